@@ -1,0 +1,165 @@
+/* csvae.h -- C ABI of the MI355X conditional-sampling library (libcsvae.so).
+ *
+ * The library implements, as hand-written HIP kernels for gfx950, the per-iteration work of
+ * the two VAE conditional samplers of vsimkus/vae-conditional-sampling:
+ *   LAIR   (irwg/sampling/vae_imputation.py:484-726, class at
+ *           irwg/sampling/test_step_vae_sampling.py:1770) and
+ *   AC-MWG (irwg/sampling/test_step_vae_sampling.py:1457-1768).
+ * The reference has no native layer; these entry points are what its Python functions bind
+ * to in this build (each declaration cites the reference code it replaces).
+ *
+ * Conventions
+ *   - every function returns 0 (CS_OK) or a negative CS_E* code; cs_last_error() returns a
+ *     thread-local message for the last failure on the calling thread;
+ *   - all tensor arguments are caller-allocated DEVICE pointers, contiguous row-major,
+ *     float32 unless stated (masks: uint8, 1 = observed; indices: int64; multinomial
+ *     uniforms: float64); the library only owns the handles it creates;
+ *   - work is enqueued asynchronously on the given hipStream_t (passed as void*; NULL = the
+ *     default stream) of the current device; no entry point synchronises the device;
+ *   - every stochastic entry point takes optional injected draws; a NULL draw pointer means
+ *     "generate with the built-in counter RNG (Philox4x32-10)" keyed by
+ *     (seed, stream, iteration, example_offset + example index, element), so results are
+ *     independent of batching and of how examples are sharded over GPUs.
+ */
+#ifndef CSVAE_H
+#define CSVAE_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CS_OK 0
+#define CS_EINVAL (-1)       /* bad argument / unsupported shape */
+#define CS_EHIP (-2)         /* a HIP runtime call failed */
+#define CS_EUNSUPPORTED (-3) /* option of the reference that this library does not implement */
+
+/* distribution families (irwg/models/vae.py:19-28, create_distribution :203-256) */
+#define CS_DIST_NORMAL 0          /* scale = softplus(raw)            */
+#define CS_DIST_NORMAL_WITH_EPS 1 /* scale = softplus(raw) + 1e-8     */
+#define CS_DIST_BERN 2            /* logits                           */
+
+/* importance weighting (vae_imputation.py:615-640) */
+#define CS_W_DMIS 0
+#define CS_W_DMIS_WITHIN_GROUPS 1
+#define CS_W_SMIS 2
+/* resampling scheme (vae_imputation.py:646-674) and method (:291-298) */
+#define CS_RS_GR 0
+#define CS_RS_GLR 1
+#define CS_RM_MULTINOMIAL 0
+#define CS_RM_SYSTEMATIC 1
+
+int cs_version(void);
+const char* cs_last_error(void);
+
+/* ---------------------------------------------------------------------------------------
+ * Residual MLP (irwg/models/neural_nets.py:106-169, ResidualFCNetwork; eval mode, ReLU,
+ * no normalisation layers).  Weights are given as HOST pointers in the state-dict layout
+ * (nn.Linear: weight[out,in] row-major, bias[out]); the library repacks them into its MFMA
+ * operand stream and uploads them to the current device.
+ *   Wblk: [num_blocks][2][hidden][hidden], bblk: [num_blocks][2][hidden]
+ * out_split = 2 when the output is a concatenation (first half | second half) of two
+ * parameter groups (loc | raw scale; vae.py:190-195), 1 otherwise.
+ * Limits: hidden in {64,128,256}; in_dim <= 128; out_dim/out_split <= 64.
+ */
+typedef struct cs_mlp cs_mlp_t;
+typedef struct {
+  int32_t in_dim, out_dim, num_blocks, hidden, out_split;
+} cs_mlp_desc;
+
+int cs_mlp_create(const cs_mlp_desc* desc, const float* W0, const float* b0, const float* Wblk,
+                  const float* bblk, const float* Wf, const float* bf, cs_mlp_t** out);
+int cs_mlp_destroy(cs_mlp_t* net);
+/* y[rows,out_dim] = net(x[rows,in_dim]); replaces ResidualFCNetwork.forward
+ * (neural_nets.py:163-169), i.e. model.var_latent_network(X) / model.generator_network(Z). */
+int cs_mlp_forward(const cs_mlp_t* net, const float* x, int64_t rows, float* y, void* stream);
+
+/* counter-RNG key */
+typedef struct {
+  uint64_t seed;
+  uint32_t iteration;
+  int64_t example_offset; /* global index of local example 0 (rank shard offset) */
+} cs_rng;
+
+/* ---------------------------------------------------------------------------------------
+ * LAIR iteration = importance_resampling_gibbs_iteration (vae_imputation.py:484-726) for
+ * weighting in {dmis, dmis_within_groups, smis}, scheme in {gr, glr}, method in
+ * {multinomial, systematic}, with R prior-replenishing proposals.  K' = K + R.
+ */
+typedef struct {
+  int32_t B, K, R, I, D, Zd;
+  int32_t latent_dist, gen_dist; /* CS_DIST_* */
+  int32_t weighting, scheme, method;
+  int32_t cluster_size; /* glr / dmis_within_groups */
+  float weight_alpha;   /* resampling uses alpha*log_w (polynomial transform,
+                           test_step_vae_sampling.py:2059-2061); 1 = none */
+} cs_lair_cfg;
+
+typedef struct {
+  float* X;         /* [B,K,D]  in: current imputations; out: new imputations (in place) */
+  const uint8_t* M; /* [B,D]    1 = observed */
+  /* injected draws, any may be NULL (-> Philox) */
+  const float* eps_z;   /* [I,B,K',Zd] standard normal */
+  const double* u_res;  /* multinomial: gr [B,K'], glr [B,G,c] */
+  const double* u_res2; /* second resampling for latents_resampled */
+  const float* u_sys;   /* systematic: gr [B], glr [B,G] */
+  const float* u_sys2;
+  const float* eps_x; /* [B,K,D] standard normal (Bernoulli generator: uniforms) */
+  /* outputs / workspace (required unless marked optional) */
+  float* q;            /* [B,K',2,Zd] proposal loc and scale (after softplus) */
+  float* Z;            /* [I,B,K',Zd] proposals */
+  float* gen;          /* [I,B,K',2,D] generator mean and scale; Bernoulli: [I,B,K',D] logits */
+  float* gen_ll;       /* [I,B,K'] masked log-likelihood of X under each proposal */
+  float* log_w;        /* [I,B,K'] */
+  float* norm_log_w;   /* [B,I*K'] (gr '(i k)'; glr '(g i c)') */
+  int64_t* idx;        /* [B,K'] source proposal (flattened i*K'+k') of output slot */
+  float* ess;          /* [B] */
+  float* tess;         /* [B] ESS of the transformed weights */
+  float* perplexity;   /* [B] */
+  float* latents_resampled; /* optional [B,K',Zd] (return_resampled_latents) */
+  int64_t* idx2;            /* optional [B,K'] indices of that second resampling */
+  const float* clip_min;    /* optional [D] (test_step_vae_sampling.py:1942-1950) */
+  const float* clip_max;
+} cs_lair_bufs;
+
+/* encoder forward + distribution parameterisation: q[b,k,:] for k < K
+ * (vae_imputation.py:551 + vae.py:214-219); rows k >= K of q are set to the prior
+ * replenishing proposal (loc 0, scale 1; vae_imputation.py:563-577). */
+int cs_lair_encode(const cs_mlp_t* enc, const cs_lair_cfg* cfg, const cs_lair_bufs* b, void* stream);
+/* Z = loc + scale*eps, decoder forward, generator parameterisation, masked log-likelihood
+ * (vae_imputation.py:596-603, weights.py:46-47). */
+int cs_lair_decode(const cs_mlp_t* dec, const cs_lair_cfg* cfg, const cs_lair_bufs* b, const cs_rng* rng,
+                   void* stream);
+/* importance weights, resampling, sampling of the missing values, in-place imputation, ESS and
+ * perplexity (weights.py:50-57,69-85; vae_imputation.py:284-308,335-378,380-458,677-726). */
+int cs_lair_resample_impute(const cs_lair_cfg* cfg, const cs_lair_bufs* b, const cs_rng* rng, void* stream);
+/* the three stages above, back to back on one stream */
+int cs_lair_step(const cs_mlp_t* enc, const cs_mlp_t* dec, const cs_lair_cfg* cfg, const cs_lair_bufs* b,
+                 const cs_rng* rng, void* stream);
+
+/* gen[rows,2,D] (mean, scale) or [rows,D] (Bernoulli logits) = generator parameterisation of
+ * generator_network(Z[rows,Zd]) (vae.py:171-172,203-256). */
+int cs_decode_params(const cs_mlp_t* dec, const float* Z, int64_t rows, int32_t gen_dist, float* gen, void* stream);
+/* x_m ~ p(x | gen) and X = X*M + x_m*(1-M) for rows (b,k), in place: pseudo_gibbs_iteration
+ * (vae_imputation.py:31-45), the 'vae_samples' initial imputation
+ * (test_step_vae_sampling.py:279-287) and the final decode of LAIR (:2019-2026).
+ * M == NULL: X = x_m.  eps[B*K,D] injected draws or NULL (-> counter RNG stream `stream_id`,
+ * row = example_offset*K + row).  clip_min/clip_max[D] (optional) bound x_m before blending.
+ * flags: CS_SI_ZERO_MISSING treats X as 0 where M = 0 (NaN-coded inputs);
+ *        CS_SI_NONFINITE_KEEP keeps the previous value where x_m is not finite. */
+#define CS_SI_ZERO_MISSING 1
+#define CS_SI_NONFINITE_KEEP 2
+int cs_sample_impute(const float* gen, int32_t gen_dist, const float* eps, const cs_rng* rng, uint32_t stream_id,
+                     float* X, const uint8_t* M, int64_t B, int32_t K, int32_t D, const float* clip_min,
+                     const float* clip_max, int32_t flags, void* stream);
+
+/* Draws the built-in RNG would use, written out for tests: standard normals / uniforms of
+ * `stream_id` (CS_STREAM_* in csrc/cs_common.h) for rows [0,rows) x elements [0,cols). */
+int cs_rng_normal(const cs_rng* rng, uint32_t stream_id, int64_t rows, int32_t cols, float* out, void* stream);
+int cs_rng_uniform(const cs_rng* rng, uint32_t stream_id, int64_t rows, int32_t cols, float* out, void* stream);
+int cs_rng_uniform64(const cs_rng* rng, uint32_t stream_id, int64_t rows, int32_t cols, double* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,158 @@
+"""Pin the oracle against the reference itself and write the golden vectors.
+
+TEST INFRASTRUCTURE ONLY; runs in the build container only (needs /root/reference).
+
+    python oracle/check_against_reference.py            # check + (re)write tests/golden/*.npz
+
+For every case it runs the reference package (through ``oracle/ref_harness.py``) on seeded
+inputs while recording the draw tape, feeds the same draws to ``oracle/cs_oracle.py`` and
+asserts equality of every intermediate (bitwise for indices / decisions; the float
+arithmetic is the same torch-CPU ops in the same order, so floats are asserted to 1e-6
+relative and are in practice identical).  The inputs, the tape and the *reference's*
+outputs are then saved as small ``.npz`` fixtures.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+
+from oracle import cs_oracle as O  # noqa: E402
+from oracle.ref_harness import DrawTape, load_reference  # noqa: E402
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def ref_resfc(ns, w):
+    H, in_dim = w["W0"].shape
+    out_dim = w["Wf"].shape[0]
+    net = ns.neural_nets.ResidualFCNetwork(in_dim, out_dim, len(w["blocks"]), H)
+    with torch.no_grad():
+        net.initial_layer.weight.copy_(w["W0"]); net.initial_layer.bias.copy_(w["b0"])
+        for blk, (W1, b1, W2, b2) in zip(net.blocks, w["blocks"]):
+            blk.linear_layers[0].weight.copy_(W1); blk.linear_layers[0].bias.copy_(b1)
+            blk.linear_layers[1].weight.copy_(W2); blk.linear_layers[1].bias.copy_(b2)
+        net.final_layer.weight.copy_(w["Wf"]); net.final_layer.bias.copy_(w["bf"])
+    return net
+
+
+def ref_vae(ns, enc, dec, latent_dist="normal_with_eps", gen_dist="normal_with_eps"):
+    D = ns.vae.DISTRIBUTION
+    vae = ns.vae.VAE(ref_resfc(ns, dec), D[gen_dist], ref_resfc(ns, enc), D[latent_dist],
+                     num_latent_samples=1, lr_generator=1e-3, lr_latent=1e-3)
+    return vae.eval()
+
+
+def flat_weights(prefix, w):
+    d = {f"{prefix}_W0": w["W0"].numpy(), f"{prefix}_b0": w["b0"].numpy(),
+         f"{prefix}_Wf": w["Wf"].numpy(), f"{prefix}_bf": w["bf"].numpy(),
+         f"{prefix}_nb": np.int64(len(w["blocks"]))}
+    for i, (W1, b1, W2, b2) in enumerate(w["blocks"]):
+        d[f"{prefix}_blk{i}_W1"] = W1.numpy(); d[f"{prefix}_blk{i}_b1"] = b1.numpy()
+        d[f"{prefix}_blk{i}_W2"] = W2.numpy(); d[f"{prefix}_blk{i}_b2"] = b2.numpy()
+    return d
+
+
+def close(a, b, what, rtol=1e-6, atol=1e-6):
+    a = a.detach().numpy() if torch.is_tensor(a) else np.asarray(a)
+    b = b.detach().numpy() if torch.is_tensor(b) else np.asarray(b)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    if a.dtype.kind in "iub":
+        assert np.array_equal(a, b), f"{what}: integer/bool mismatch"
+    else:
+        assert np.allclose(a, b, rtol=rtol, atol=atol, equal_nan=True), \
+            f"{what}: max abs diff {np.nanmax(np.abs(a - b))}"
+
+
+def make_inputs(B, K, D, seed, miss=0.5):
+    g = torch.Generator().manual_seed(seed)
+    X_true = torch.randn(B, D, generator=g)
+    M = torch.rand(B, D, generator=g) > miss
+    M[:, 0] = True  # no fully-missing rows (the reference filters them)
+    X = X_true.unsqueeze(1).repeat(1, K, 1)
+    X = X * M.unsqueeze(1) + torch.randn(B, K, D, generator=g) * (~M.unsqueeze(1))
+    return X.contiguous(), M.unsqueeze(1).contiguous()
+
+
+# ----------------------------------------------------------------------------------------
+def case_lair(ns, name, *, B, K, R, I, D, Zd, H, nb_enc, nb_dec, seed, scheme="gr",
+              weighting="dmis", method="multinomial", cluster=None, resampled_latents=False,
+              iters=2):
+    enc = O.make_resfc_weights(D, 2 * Zd, nb_enc, H, seed)
+    dec = O.make_resfc_weights(Zd, 2 * D, nb_dec, H, seed + 1)
+    vae = ref_vae(ns, enc, dec)
+    X, M = make_inputs(B, K, D, seed + 2)
+    fx = dict(flat_weights("enc", enc)); fx.update(flat_weights("dec", dec))
+    fx.update(X0=X.numpy(), M=M.numpy(),
+              cfg=np.array([B, K, R, I, D, Zd, H, cluster or 0, iters], dtype=np.int64),
+              scheme=np.array(scheme), weighting=np.array(weighting), method=np.array(method),
+              resampled_latents=np.array(resampled_latents))
+    tape = DrawTape(seed + 3)
+    Xr = X.clone()
+    for t in range(iters):
+        n0 = len(tape.entries)
+        with torch.no_grad(), tape.recording():
+            ret = ns.vae_imputation.importance_resampling_gibbs_iteration(
+                vae, Xr, M, I, glr_cluster_size=cluster, weighting=weighting,
+                resampling_method=method, resampling_scheme=scheme,
+                num_prior_replenish_proposals=R, return_resampled_latents=resampled_latents)
+        ent = tape.entries[n0:]
+        kinds = [k for k, _ in ent]
+        res_kind = "multinomial" if method == "multinomial" else "rand"
+        expect = ["normal", res_kind] + ([res_kind] if resampled_latents else []) + ["normal"]
+        assert kinds == expect, kinds
+        draws = {"eps_z": torch.from_numpy(ent[0][1]), "u_res": torch.from_numpy(ent[1][1]),
+                 "eps_x": torch.from_numpy(ent[-1][1])}
+        if resampled_latents:
+            draws["u_res2"] = torch.from_numpy(ent[2][1])
+        o = O.lair_iteration(enc, dec, Xr, M, draws, num_imp_samples=I, weighting=weighting,
+                             resampling_scheme=scheme, resampling_method=method,
+                             glr_cluster_size=cluster, num_prior_replenish_proposals=R,
+                             return_resampled_latents=resampled_latents)
+        close(o["X_new"], ret[0], "X_new"); close(o["ess"], ret[1], "ess")
+        close(o["transformed_ess"], ret[2], "tess"); close(o["perplexity"], ret[3], "perplexity")
+        assert o["total_num_props"] == ret[4]
+        close(o["norm_log_weights"], ret[5], "norm_log_weights")
+        close(o["Z_imp"], ret[6], "Z_imp"); close(o["log_weights"], ret[7], "log_weights")
+        assert torch.equal(o["X_new"], ret[0]), "X_new not bitwise equal"
+        assert torch.equal(o["log_weights"], ret[7]), "log_weights not bitwise equal"
+        if resampled_latents:
+            close(o["latents_resampled"][:, :K] if False else o["latents_resampled"], ret[9], "latents_resampled")
+        # the reference does not return indices: recover them from its outputs for the fixture
+        fx.update({f"t{t}_eps_z": ent[0][1], f"t{t}_u_res": ent[1][1], f"t{t}_eps_x": ent[-1][1],
+                   f"t{t}_X_new": ret[0].numpy(), f"t{t}_ess": ret[1].numpy(),
+                   f"t{t}_perplexity": ret[3].numpy(), f"t{t}_norm_log_weights": ret[5].numpy(),
+                   f"t{t}_Z_imp": ret[6].numpy(), f"t{t}_log_weights": ret[7].numpy(),
+                   f"t{t}_idx": o["idx_global"].numpy(),
+                   f"t{t}_q_loc": o["q_loc"].numpy(), f"t{t}_q_scale": o["q_scale"].numpy(),
+                   f"t{t}_gen_params": o["generator_params"].numpy()})
+        if resampled_latents:
+            fx[f"t{t}_u_res2"] = ent[2][1]
+            fx[f"t{t}_latents_resampled"] = ret[9].numpy()
+        Xr = ret[0]
+    np.savez_compressed(os.path.join(GOLDEN, f"{name}.npz"), **fx)
+    print(f"[ok] {name}")
+
+
+def main():
+    os.makedirs(GOLDEN, exist_ok=True)
+    ns = load_reference()
+    torch.manual_seed(0)
+    case_lair(ns, "lair_gr_mult_small", B=6, K=4, R=1, I=1, D=11, Zd=5, H=64, nb_enc=2, nb_dec=1, seed=101)
+    case_lair(ns, "lair_gr_mult_i2_lat", B=5, K=3, R=2, I=2, D=9, Zd=4, H=64, nb_enc=1, nb_dec=2, seed=202,
+              resampled_latents=True)
+    case_lair(ns, "lair_gr_mult_noreplenish", B=4, K=5, R=0, I=1, D=8, Zd=16, H=64, nb_enc=1, nb_dec=1, seed=303)
+    case_lair(ns, "lair_gr_syst", B=6, K=4, R=1, I=1, D=11, Zd=5, H=64, nb_enc=1, nb_dec=1, seed=404,
+              method="systematic")
+    case_lair(ns, "lair_glr_groups", B=4, K=20, R=5, I=1, D=10, Zd=6, H=64, nb_enc=1, nb_dec=1, seed=505,
+              scheme="glr", weighting="dmis_within_groups", cluster=5)
+    case_lair(ns, "lair_miniboone_shape", B=3, K=4, R=1, I=1, D=43, Zd=32, H=256, nb_enc=5, nb_dec=2, seed=606,
+              iters=1)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,503 @@
+"""CPU oracle for the conditional-sampling hot path (LAIR and AC-MWG iterations).
+
+TEST INFRASTRUCTURE ONLY -- this file is the *checker*.  Only ``tests/``,
+``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of ``bench.py`` may import it.
+The product package (``vae_conditional_sampling_amd``) never does; its compute runs in
+the HIP library and fails loudly when that library is missing.
+
+It is a from-scratch restatement, in plain float32 torch-CPU tensor arithmetic, of what
+the reference computes on the path, with every random draw made an explicit input
+("injected draws") so that the reference, this oracle and the HIP engine can be fed the
+same numbers.  Parity pinning: ``oracle/check_against_reference.py`` runs the reference
+package itself (importable in the build container only) on seeded inputs with a recorded
+draw tape and asserts this file reproduces every intermediate; the vectors it writes are
+committed under ``tests/golden/`` and re-checked by ``tests/test_oracle_golden.py``.
+The reference's own self-tests for the path (history-queue known-answer test, DM-MIS
+vs nested loops, systematic-resampling histogram) are re-expressed in
+``tests/test_oracle_reference_selftests.py``.
+
+Reference locations restated here (paths relative to the reference root):
+  * residual MLP forward                irwg/models/neural_nets.py:87-103,163-169
+  * distribution parameterisation       irwg/models/vae.py:203-256  (softplus + 1e-8)
+  * prior, unconditional sample         irwg/models/vae.py:158-178
+  * DM-MIS log-weights                  irwg/utils/weights.py:37-85
+  * grouped DM-MIS                      irwg/sampling/vae_imputation.py:380-458
+  * gr / glr resampling                 irwg/sampling/vae_imputation.py:284-308,335-378
+  * systematic resampling               irwg/sampling/vae_imputation.py:804-834
+  * LAIR iteration                      irwg/sampling/vae_imputation.py:484-726
+  * pseudo-Gibbs iteration              irwg/sampling/vae_imputation.py:19-45
+  * AC-MWG step                         irwg/sampling/test_step_vae_sampling.py:1664-1768
+  * restricted-availability history     irwg/sampling/utils.py:83-237
+  * LAIR final resampling               irwg/sampling/test_step_vae_sampling.py:1979-2045
+Arithmetic that lives in torch itself (Normal/Bernoulli log-pdf, softplus, multinomial)
+is restated from the installed torch's published formulas.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+EPSILON = 1e-8  # irwg/models/vae.py:16
+LOG_SQRT_2PI = math.log(math.sqrt(2 * math.pi))
+
+
+# --------------------------------------------------------------------------------------
+# networks
+# --------------------------------------------------------------------------------------
+def make_resfc_weights(in_dim, out_dim, num_blocks, hidden, seed):
+    """Random weights with torch's default nn.Linear initialisation (kaiming-uniform,
+    a=sqrt(5)) for a residual MLP of the reference's shape.  Returns a dict of float32
+    torch tensors: W0[H,in] b0[H]; blocks: list of (W1[H,H], b1[H], W2[H,H], b2[H]);
+    Wf[out,H] bf[out]."""
+    g = torch.Generator().manual_seed(seed)
+
+    def lin(o, i):
+        bound = 1.0 / math.sqrt(i)
+        W = (torch.rand(o, i, generator=g) * 2 - 1) * bound
+        b = (torch.rand(o, generator=g) * 2 - 1) * bound
+        return W.float(), b.float()
+
+    W0, b0 = lin(hidden, in_dim)
+    blocks = []
+    for _ in range(num_blocks):
+        W1, b1 = lin(hidden, hidden)
+        W2, b2 = lin(hidden, hidden)
+        blocks.append((W1, b1, W2, b2))
+    Wf, bf = lin(out_dim, hidden)
+    return {"W0": W0, "b0": b0, "blocks": blocks, "Wf": Wf, "bf": bf}
+
+
+def resfc_forward(w, x):
+    """h = relu(W0 x + b0); per block h = relu(h + W2 relu(W1 h + b1) + b2); y = Wf h + bf.
+    (neural_nets.py:163-169 with :87-103; dropout is identity in eval mode; no norm layers
+    in the configurations on the path.)"""
+    h = F.relu(F.linear(x, w["W0"], w["b0"]))
+    for (W1, b1, W2, b2) in w["blocks"]:
+        t = F.relu(F.linear(h, W1, b1))
+        h = F.relu(h + F.linear(t, W2, b2))
+    return F.linear(h, w["Wf"], w["bf"])
+
+
+# --------------------------------------------------------------------------------------
+# distributions (vae.py:203-256 + torch.distributions formulas)
+# --------------------------------------------------------------------------------------
+def split_loc_scale(params, dist):
+    """'... (2 d) -> loc, scale' with scale = softplus(raw) (+1e-8 for normal_with_eps)."""
+    d = params.shape[-1] // 2
+    loc, raw = params[..., :d], params[..., d:]
+    scale = F.softplus(raw)
+    if dist == "normal_with_eps":
+        scale = scale + EPSILON
+    elif dist != "normal":
+        raise NotImplementedError(dist)
+    return loc, scale
+
+
+def normal_log_prob(x, loc, scale):
+    """torch.distributions.Normal.log_prob: -(x-loc)^2/(2 var) - log(scale) - log(sqrt(2 pi))."""
+    var = scale ** 2
+    return -((x - loc) ** 2) / (2 * var) - scale.log() - LOG_SQRT_2PI
+
+
+def std_normal_log_prob(z):
+    """Normal(0.,1.).log_prob(z) (prior, vae.py:162).  The reference's prior holds 0-dim
+    float32 tensors loc=0, scale=1: var=1, log(scale)=0."""
+    one = torch.tensor(1.0)
+    return -((z - torch.tensor(0.0)) ** 2) / (2 * one ** 2) - one.log() - LOG_SQRT_2PI
+
+
+def bernoulli_log_prob(x, logits):
+    """torch.distributions.Bernoulli(logits).log_prob = -BCEWithLogits(logits, x)."""
+    return -F.binary_cross_entropy_with_logits(logits, x, reduction="none")
+
+
+def gen_log_prob(x, params, dist):
+    if dist == "bern":
+        return bernoulli_log_prob(x, params)
+    loc, scale = split_loc_scale(params, dist)
+    return normal_log_prob(x, loc, scale)
+
+
+def gen_sample(params, dist, draw):
+    """Sample of the generator distribution from an injected draw: standard-normal eps for
+    the Normal families (torch.normal(loc, scale) == loc + scale*eps bitwise on CPU),
+    float32 uniform u for Bernoulli (torch.bernoulli(p) == (u < p))."""
+    if dist == "bern":
+        return (draw < torch.sigmoid(params)).to(params.dtype)
+    loc, scale = split_loc_scale(params, dist)
+    return loc + scale * draw
+
+
+def softplus_inverse(x):
+    """irwg/utils/softplus_inverse.py:3-7"""
+    return x + torch.log(-torch.expm1(-x))
+
+
+def replenish_params(B, R, Zd, dist):
+    """Raw proposal parameters of the R prior-replenishing proposals
+    (vae_imputation.py:563-577): loc 0, raw scale softplus^-1(1 [- 1e-8])."""
+    means = torch.zeros(B, R, Zd)
+    scales = torch.ones(B, R, Zd)
+    if dist == "normal":
+        raw = softplus_inverse(scales)
+    elif dist == "normal_with_eps":
+        raw = softplus_inverse(scales - EPSILON)
+    else:
+        raise NotImplementedError(dist)
+    return torch.cat([means, raw], dim=-1)
+
+
+# --------------------------------------------------------------------------------------
+# categorical sampling with injected uniforms
+# --------------------------------------------------------------------------------------
+def categorical_probs(logits):
+    """torch.distributions.Categorical(logits=l).probs: l - logsumexp(l), then softmax."""
+    nl = logits - logits.logsumexp(dim=-1, keepdim=True)
+    return F.softmax(nl, dim=-1)
+
+
+def multinomial_indices(probs, u):
+    """torch.multinomial(probs[rows,S], n>1, replacement=True) on CPU with its float64
+    uniforms u[rows,n] made explicit: float32 running sum, divide by the total, force the
+    last entry to 1, index = number of entries with cum < u (left bisection)."""
+    p = probs.detach().to(torch.float32).numpy()
+    u = np.asarray(u, dtype=np.float64)
+    rows, S = p.shape
+    out = np.empty(u.shape, dtype=np.int64)
+    for r in range(rows):
+        cum = np.cumsum(p[r], dtype=np.float32)  # sequential float32 accumulation
+        cum = (cum / cum[-1]).astype(np.float32)
+        cum[-1] = np.float32(1.0)
+        out[r] = np.searchsorted(cum.astype(np.float64), u[r], side="left")
+    return torch.from_numpy(out)
+
+
+def systematic_indices(log_weights, U, num_dependent_samples):
+    """vae_imputation.py:804-834 with its one uniform per row, U[..., 1] float32, injected."""
+    lw = log_weights - torch.logsumexp(log_weights, dim=-1, keepdim=True)
+    probs = torch.exp(lw)
+    probs = probs / probs.sum(dim=-1, keepdim=True)
+    m = num_dependent_samples
+    n = probs.cumsum(-1).mul(m).add(U)
+    n = n.floor().clamp(min=0, max=m).long()
+    diff = probs.new_zeros(probs.shape[:-1] + (m + 1,))
+    diff.scatter_add_(-1, n, torch.ones_like(probs))
+    return diff[..., :-1].cumsum(-1).long()
+
+
+# --------------------------------------------------------------------------------------
+# importance weights
+# --------------------------------------------------------------------------------------
+def dmis_mixture_logprob(Z, q_loc, q_scale):
+    """log of the deterministic-mixture proposal density at every proposal
+    (weights.py:69-85).  Z[I,B,K,Zd], q_loc/q_scale[B,K,Zd] -> [I,B,K]:
+    logsumexp_j sum_d log N(Z[i,b,k]; loc[b,j], scale[b,j]) - log K."""
+    K = Z.shape[2]
+    # comp[j,i,b,k] = sum_d log N(Z[i,b,k,d]; loc[b,j,d], scale[b,j,d])
+    Zs = Z.unsqueeze(0).transpose(0, -2)  # [K(k),I,B,1,Zd]  (value k sits on axis 0)
+    lp = normal_log_prob(Zs, q_loc, q_scale)  # broadcast -> [K(k),I,B,K(j),Zd]
+    lp = lp.sum(-1)
+    lp = torch.logsumexp(lp, dim=-1, keepdim=True)
+    lp = lp - torch.log(torch.tensor(K))
+    return lp.transpose(0, -1).squeeze(0)  # [I,B,K]
+
+
+def grouped_dmis_mixture_logprob(Z, q_loc, q_scale, cluster_size):
+    """Mixture restricted to the proposal's own group (vae_imputation.py:407-434, no
+    padding).  Layout '(c k)': member j belongs to group j mod (K/c); a group has c members."""
+    I, B, K, Zd = Z.shape
+    c = cluster_size
+    G = K // c
+    Zg = Z.reshape(I, B, c, G, Zd).permute(0, 1, 3, 2, 4)        # i b g c d
+    loc = q_loc.reshape(B, c, G, Zd).permute(0, 2, 1, 3)          # b g c d
+    scale = q_scale.reshape(B, c, G, Zd).permute(0, 2, 1, 3)
+    Zs = Zg.unsqueeze(0).transpose(0, -2)                        # [c(val),I,B,G,1,Zd]
+    lp = normal_log_prob(Zs, loc, scale).sum(-1)                  # [c(val),I,B,G,c(comp)]
+    lp = torch.logsumexp(lp, dim=-1, keepdim=True)
+    lp = lp - torch.log(torch.tensor(c))
+    lp = lp.transpose(0, -1).squeeze(0)                           # [I,B,G,c]
+    return lp.permute(0, 1, 3, 2).reshape(I, B, K)                # i b (c g)
+
+
+def lair_log_weights(X, M, Z, q_loc, q_scale, gen_params, gen_dist, weighting, cluster_size=None):
+    """log w = sum_d M log p(x_d|z) + sum log p(z) - log q_mix(z)  (weights.py:46-57)."""
+    gl = (gen_log_prob(X, gen_params, gen_dist) * M).sum(-1)
+    pl = std_normal_log_prob(Z).sum(-1)
+    if weighting == "dmis":
+        ql = dmis_mixture_logprob(Z, q_loc, q_scale)
+    elif weighting == "dmis_within_groups":
+        ql = grouped_dmis_mixture_logprob(Z, q_loc, q_scale, cluster_size)
+    elif weighting == "smis":
+        ql = normal_log_prob(Z, q_loc, q_scale).sum(-1)
+    else:
+        raise NotImplementedError(weighting)
+    return gl + pl - ql, gl, pl, ql
+
+
+# --------------------------------------------------------------------------------------
+# resampling
+# --------------------------------------------------------------------------------------
+def gr_resample(log_w, u, method="multinomial"):
+    """Global resampling (vae_imputation.py:284-308).  log_w[I,B,K'] -> idx[B,K'] into the
+    flattened '(i k)' axis, and normalised log-weights [B, I*K'].  ``u`` is float64
+    [B,K'] for multinomial, float32 [B,1] for systematic."""
+    I, B, K = log_w.shape
+    lw = log_w.permute(1, 0, 2).reshape(B, I * K)
+    if method == "multinomial":
+        idx = multinomial_indices(categorical_probs(lw), u)
+    elif method == "systematic":
+        idx = systematic_indices(lw, u, K)
+    else:
+        raise NotImplementedError(method)
+    return idx, lw - lw.logsumexp(dim=-1, keepdim=True)
+
+
+def gather_gr(params, idx):
+    """params[I,B,K',P] -> [B,n,P] taking flattened '(i k)' index idx[B,n]."""
+    I, B, K = params.shape[:3]
+    flat = params.permute(1, 0, 2, 3).reshape(B, I * K, -1)
+    return flat[torch.arange(B)[:, None], idx]
+
+
+def glr_resample(log_w, u, cluster_size, method="multinomial"):
+    """Global-local resampling (vae_imputation.py:335-378, no padding).  Group g holds the
+    members j with j mod G == g (G = K'/c); it draws c indices among its I*c members laid
+    out '(i c)'.  Returns local idx[B,G,c] (draw t of group g), the flattened global
+    '(i k)' index of every output slot in the reference's output order '(c k)'
+    (slot t*G+g), and norm_log_weights[B, G*I*c]."""
+    I, B, K = log_w.shape
+    c = cluster_size
+    G = K // c
+    lw = log_w.reshape(I, B, c, G).permute(1, 3, 0, 2).reshape(B, G, I * c)  # b g (i c)
+    if method == "multinomial":
+        probs = categorical_probs(lw).reshape(B * G, I * c)
+        idx = multinomial_indices(probs, np.asarray(u).reshape(B * G, c)).reshape(B, G, c)
+    elif method == "systematic":
+        idx = systematic_indices(lw, torch.as_tensor(u).reshape(B, G, 1), c)
+    else:
+        raise NotImplementedError(method)
+    # local (i, cc) -> global proposal index cc*G + g within importance sample i
+    i_loc = idx // c
+    c_loc = idx % c
+    g_ar = torch.arange(G)[None, :, None]
+    glob = i_loc * K + c_loc * G + g_ar                       # [B,G,c] flattened (i k)
+    glob_out = glob.permute(0, 2, 1).reshape(B, c * G)        # slot t*G+g
+    nlw = lw - lw.logsumexp(dim=-1, keepdim=True)
+    return idx, glob_out, nlw.reshape(B, G * I * c)
+
+
+# --------------------------------------------------------------------------------------
+# LAIR iteration
+# --------------------------------------------------------------------------------------
+def lair_iteration(enc, dec, X, M, draws, *, num_imp_samples=1, weighting="dmis",
+                   resampling_scheme="gr", resampling_method="multinomial",
+                   glr_cluster_size=None, num_prior_replenish_proposals=0,
+                   latent_dist="normal_with_eps", gen_dist="normal_with_eps",
+                   return_resampled_latents=False, weight_alpha=None,
+                   encoder=None, decoder=None):
+    """One LAIR step (vae_imputation.py:484-726) with injected draws.
+
+    X[B,K,D] float32, M[B,1,D] bool.  draws: 'eps_z'[I,B,K',Zd], 'u_res' (float64
+    [B,K'] for gr / [B*G,c] for glr multinomial; float32 [B,1] / [B,G,1] systematic),
+    optional 'u_res2' (same shape, used when return_resampled_latents),
+    'eps_x'[B,K,D] (uniforms for Bernoulli).  ``encoder``/``decoder`` override the MLP
+    forward (used for the conv nets)."""
+    encoder = encoder or (lambda x: resfc_forward(enc, x))
+    decoder = decoder or (lambda z: resfc_forward(dec, z))
+    B, K, D = X.shape
+    R = num_prior_replenish_proposals
+    I = num_imp_samples
+    Mf = M  # bool [B,1,D]
+    out = {}
+
+    var_params = encoder(X)                                   # [B,K,2Zd]
+    Zd = var_params.shape[-1] // 2
+    Xp = X
+    if R > 0:
+        var_params = torch.cat([var_params, replenish_params(B, R, Zd, latent_dist)], dim=1)
+        Xp = torch.cat([X, X[:, :1].expand(B, R, D)], dim=1)
+    q_loc, q_scale = split_loc_scale(var_params, latent_dist)
+    Kp = K + R
+    Z = q_loc + q_scale * draws["eps_z"]                      # [I,B,K',Zd]
+    gen_params = decoder(Z)                                   # [I,B,K',P]
+    log_w, gl, pl, ql = lair_log_weights(Xp, Mf, Z, q_loc, q_scale, gen_params, gen_dist,
+                                         weighting, glr_cluster_size)
+    t_log_w = log_w if weight_alpha is None else log_w * weight_alpha
+
+    def resample(u):
+        if resampling_scheme == "gr":
+            idx, nlw = gr_resample(t_log_w, u, resampling_method)
+            return idx, idx, nlw
+        if resampling_scheme == "glr":
+            loc_idx, glob, nlw = glr_resample(t_log_w, u, glr_cluster_size, resampling_method)
+            return loc_idx, glob, nlw
+        raise NotImplementedError(resampling_scheme)
+
+    idx_raw, idx_glob, norm_log_w = resample(draws["u_res"])
+    mis_params = gather_gr(gen_params, idx_glob)              # [B,K',P]
+    latents_resampled = None
+    if return_resampled_latents:
+        _, idx2, _ = resample(draws["u_res2"])
+        latents_resampled = gather_gr(Z, idx2)
+        out["idx2"] = idx2
+    mis_params = mis_params[:, :K]
+    X_m = gen_sample(mis_params, gen_dist, draws["eps_x"])
+    X_new = X * Mf + X_m * (~Mf)
+
+    lwr = log_w.permute(1, 0, 2).reshape(B, I * Kp)
+    lnw = lwr - torch.logsumexp(lwr, dim=-1, keepdim=True)
+    ess = torch.exp(-torch.logsumexp(2 * lnw, -1))
+    tlwr = t_log_w.permute(1, 0, 2).reshape(B, I * Kp)
+    tlnw = tlwr - torch.logsumexp(tlwr, dim=-1, keepdim=True)
+    tess = torch.exp(-torch.logsumexp(2 * tlnw, -1))
+    perplexity = torch.exp(-torch.sum(lnw * torch.exp(lnw), dim=-1))
+
+    out.update(dict(X_new=X_new, ess=ess, transformed_ess=tess, perplexity=perplexity,
+                    total_num_props=I * Kp, norm_log_weights=norm_log_w, Z_imp=Z,
+                    log_weights=log_w, q_loc=q_loc, q_scale=q_scale, var_params=var_params,
+                    generator_params=gen_params, gen_loglik=gl, prior_logprob=pl,
+                    mix_logprob=ql, idx=idx_raw, idx_global=idx_glob, mis_params=mis_params,
+                    X_m=X_m, latents_resampled=latents_resampled))
+    return out
+
+
+def pseudo_gibbs_iteration(enc, dec, X, M, draws, *, latent_dist="normal_with_eps",
+                           gen_dist="normal_with_eps", clip_min=None, clip_max=None,
+                           encoder=None, decoder=None):
+    """vae_imputation.py:19-45.  draws: 'eps_z'[B,K,Zd], 'eps_x'[B,K,D]."""
+    encoder = encoder or (lambda x: resfc_forward(enc, x))
+    decoder = decoder or (lambda z: resfc_forward(dec, z))
+    q_loc, q_scale = split_loc_scale(encoder(X), latent_dist)
+    Z = q_loc + q_scale * draws["eps_z"]
+    params = decoder(Z)
+    X_m = gen_sample(params, gen_dist, draws["eps_x"])
+    if clip_min is not None:
+        X_m = torch.max(X_m, clip_min)
+    if clip_max is not None:
+        X_m = torch.min(X_m, clip_max)
+    bad = ~X_m.isfinite()
+    X_m = torch.where(bad, X, X_m)
+    return X * M + X_m * (~M), Z
+
+
+def vae_samples_imputation(dec, X, M, draws, *, gen_dist="normal_with_eps", decoder=None):
+    """Initial imputation from unconditional model samples
+    (test_step_vae_sampling.py:279-287 with vae.py:166-178).  draws: 'z'[B*K,Zd] standard
+    normal, 'eps_x'[B*K,D]."""
+    decoder = decoder or (lambda z: resfc_forward(dec, z))
+    B, K, D = X.shape
+    X_imp = gen_sample(decoder(draws["z"]), gen_dist, draws["eps_x"]).reshape(B, K, D)
+    Xc = X.clone()
+    Xc[(~M).expand(B, K, D)] = 0.0
+    return Xc * M + X_imp * (~M)
+
+
+def final_resample(latent_proposals, log_weights, u, num_samples):
+    """LAIR final resampling over all T*I*K' stored proposals
+    (test_step_vae_sampling.py:1998-2009).  latent_proposals[T,I,B,K',Zd],
+    log_weights[T,I,B,K'], u float64 [B,num_samples] -> idx[B,n], Z[B,n,Zd]."""
+    T, I, B, Kp, Zd = latent_proposals.shape
+    lp = latent_proposals.permute(2, 0, 1, 3, 4).reshape(B, T * I * Kp, Zd)
+    lw = log_weights.permute(2, 0, 1, 3).reshape(B, T * I * Kp)
+    idx = multinomial_indices(categorical_probs(lw), u)
+    Z = lp[torch.arange(B)[:, None], idx]
+    return idx, Z
+
+
+# --------------------------------------------------------------------------------------
+# AC-MWG
+# --------------------------------------------------------------------------------------
+class RestrictedHistory:
+    """irwg/sampling/utils.py:83-237 with the per-chain integer draws injected.
+
+    Ring of past imputations ``[T,B,K,D]`` and per-chain availability counters.  The
+    reference draws ``randint(0, max(avail,1))`` per chain (b-major); here the caller passes
+    float64 uniforms or the integers themselves."""
+
+    def __init__(self, max_len, batch_shape, dtype=torch.float32):
+        self.T = max_len
+        self.tail = -1
+        self.full = False
+        self.queue = torch.zeros((max_len,) + tuple(batch_shape), dtype=dtype)
+        self.avail = torch.zeros(tuple(batch_shape)[:2], dtype=torch.int64)
+
+    def __len__(self):
+        assert self.tail > -1
+        return self.T if self.full else self.tail + 1
+
+    def update_available(self, mask):
+        self.avail[mask] = len(self)
+
+    def enqueue(self, X):
+        if self.full:
+            self.avail -= 1
+            self.avail[self.avail < 0] = 0
+        self.tail = (self.tail + 1) % self.T
+        if self.tail == self.T - 1:
+            self.full = True
+        self.queue[self.tail] = X
+
+    def draw_bounds(self):
+        """Exclusive upper bound of each chain's integer draw: max(avail, 1)."""
+        return torch.clamp(self.avail, min=1)
+
+    def slots_from_draws(self, r):
+        """Ring slot for integer draws r[B,K] in [0, bound)."""
+        if self.full:
+            return (r + self.tail + 1) % self.T
+        return r
+
+    def gather(self, slots):
+        B, K = slots.shape
+        return self.queue[slots, torch.arange(B)[:, None], torch.arange(K)[None, :]]
+
+
+def acmwg_step(enc, dec, state, M, hist_X, draws, *, prior_mixture_probability,
+               latent_dist="normal_with_eps", gen_dist="normal_with_eps",
+               encoder=None, decoder=None):
+    """One AC-MWG step (test_step_vae_sampling.py:1671-1755).
+
+    state: dict X[B,K,D], Z_old[B,K,Zd], mis_params_old[B,K,P], Z_old_prior_logprob[B,K],
+    X_old_logprob[B,K].  hist_X[B,K,D] is the historical imputation the proposal conditions
+    on.  draws: 'eps_z'[B,K,Zd], 'z_prior'[B,K,Zd] (standard normal), 'u_prior'[B,K]
+    float32, 'u_accept'[B,K] float32, 'eps_x'[B,K,D]."""
+    encoder = encoder or (lambda x: resfc_forward(enc, x))
+    decoder = decoder or (lambda z: resfc_forward(dec, z))
+    X, Z_old = state["X"], state["Z_old"]
+    p = prior_mixture_probability
+    q_loc, q_scale = split_loc_scale(encoder(hist_X), latent_dist)
+    Z_new = q_loc + q_scale * draws["eps_z"]
+    out = {}
+    if p > 0.0:
+        use_prior = draws["u_prior"] < torch.ones_like(draws["u_prior"]) * p
+        Z_new = torch.where(use_prior.unsqueeze(-1), draws["z_prior"], Z_new)
+        out["use_prior"] = use_prior
+    zn_q = normal_log_prob(Z_new, q_loc, q_scale).sum(-1)
+    zo_q = normal_log_prob(Z_old, q_loc, q_scale).sum(-1)
+    if p > 0.0:
+        zn_p = std_normal_log_prob(Z_new).sum(-1)
+        zo_p = std_normal_log_prob(Z_old).sum(-1)
+        lp = torch.log(torch.tensor(p))
+        lq = torch.log(torch.tensor(1 - p))
+        zn_q = torch.logsumexp(torch.stack([zn_q + lq, zn_p + lp]), dim=0)
+        zo_q = torch.logsumexp(torch.stack([zo_q + lq, zo_p + lp]), dim=0)
+    zn_prior = std_normal_log_prob(Z_new).sum(-1)
+    mis_params = decoder(Z_new)
+    x_new_lp = (gen_log_prob(X, mis_params, gen_dist) * M).sum(-1)
+    log_accept = (x_new_lp + zn_prior) - (state["X_old_logprob"] + state["Z_old_prior_logprob"]) \
+        + (zo_q - zn_q)
+    accepted = draws["u_accept"] < torch.exp(log_accept)
+    na = ~accepted
+    Z_upd = Z_old * na.unsqueeze(-1) + Z_new * accepted.unsqueeze(-1)
+    zp_upd = state["Z_old_prior_logprob"] * na + zn_prior * accepted
+    mp_upd = state["mis_params_old"] * na.unsqueeze(-1) + mis_params * accepted.unsqueeze(-1)
+    X_m = gen_sample(mp_upd, gen_dist, draws["eps_x"])
+    X_new = X * M + X_m * (~M)
+    x_old_lp = (gen_log_prob(X_new, mp_upd, gen_dist) * M).sum(-1)
+    new_state = dict(X=X_new, Z_old=Z_upd, mis_params_old=mp_upd, Z_old_prior_logprob=zp_upd,
+                     X_old_logprob=x_old_lp)
+    out.update(dict(state=new_state, accepted=accepted, log_accept=log_accept, Z_new=Z_new,
+                    q_loc=q_loc, q_scale=q_scale, mis_params=mis_params,
+                    acceptance=accepted.float().mean()))
+    return out

@@ -1,0 +1,60 @@
+"""Shared helpers for the tests: golden-fixture loading, tolerances."""
+import os
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+# north-star tolerance: log-weights and imputations agree to <= 1e-5 relative in fp32
+RTOL = 1e-5
+
+
+def load_golden(name):
+    return dict(np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False))
+
+
+def weights_from_fixture(fx, prefix):
+    nb = int(fx[f"{prefix}_nb"])
+    t = lambda k: torch.from_numpy(fx[k])
+    blocks = [(t(f"{prefix}_blk{i}_W1"), t(f"{prefix}_blk{i}_b1"), t(f"{prefix}_blk{i}_W2"), t(f"{prefix}_blk{i}_b2"))
+              for i in range(nb)]
+    return {"W0": t(f"{prefix}_W0"), "b0": t(f"{prefix}_b0"), "blocks": blocks,
+            "Wf": t(f"{prefix}_Wf"), "bf": t(f"{prefix}_bf")}
+
+
+def rel_err(a, b):
+    """max |a-b| / (|b| + 1): relative for large values, absolute near zero."""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return float(np.max(np.abs(a - b) / (np.abs(b) + 1.0))) if a.size else 0.0
+
+
+def assert_close(a, b, what, rtol=RTOL):
+    a = a.detach().cpu().numpy() if torch.is_tensor(a) else np.asarray(a)
+    b = b.detach().cpu().numpy() if torch.is_tensor(b) else np.asarray(b)
+    assert a.shape == b.shape, f"{what}: shape {a.shape} vs {b.shape}"
+    e = rel_err(a, b)
+    assert e <= rtol, f"{what}: relative error {e:.3e} > {rtol:.1e}"
+
+
+def make_model(enc_w, dec_w, latent_dist="normal_with_eps", gen_dist="normal_with_eps", device="cuda"):
+    """Product-side VAE (HIP engine) holding the given weight dicts."""
+    from vae_conditional_sampling_amd.models import ResidualFCNetwork, VAE
+    H, D = enc_w["W0"].shape
+    Zd2 = enc_w["Wf"].shape[0]
+    enc = ResidualFCNetwork(D, Zd2, len(enc_w["blocks"]), H).load_weight_dict(enc_w)
+    dec = ResidualFCNetwork(dec_w["W0"].shape[1], dec_w["Wf"].shape[0], len(dec_w["blocks"]),
+                            dec_w["W0"].shape[0]).load_weight_dict(dec_w)
+    return VAE(dec, gen_dist, enc, latent_dist).to(device)
+
+
+def seeded_inputs(B, K, D, seed, miss=0.5):
+    g = torch.Generator().manual_seed(seed)
+    X_true = torch.randn(B, D, generator=g)
+    M = torch.rand(B, D, generator=g) > miss
+    M[:, 0] = True
+    X = X_true.unsqueeze(1).repeat(1, K, 1)
+    X = X * M.unsqueeze(1) + torch.randn(B, K, D, generator=g) * (~M.unsqueeze(1))
+    return X.contiguous(), M.unsqueeze(1).contiguous()

@@ -1,0 +1,155 @@
+"""ctypes binding of libcsvae.so (the C ABI declared in include/csvae.h).
+
+There is no CPU fallback: if the shared library is missing or a call fails, an exception is
+raised.  Tensors are passed as raw device pointers (``tensor.data_ptr()``) together with the
+current HIP stream of PyTorch.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcsvae.so")
+
+CS_DIST = {"normal": 0, "normal_with_eps": 1, "bern": 2}
+CS_WEIGHTING = {"dmis": 0, "dmis_within_groups": 1, "smis": 2}
+CS_SCHEME = {"gr": 0, "glr": 1}
+CS_METHOD = {"multinomial": 0, "systematic": 1}
+
+# stream ids of the counter RNG (csrc/cs_common.h, enum CsStream)
+STREAM_Z, STREAM_X, STREAM_URES, STREAM_URES2 = 1, 2, 3, 4
+STREAM_ZPRIOR, STREAM_UPRIOR, STREAM_UACC, STREAM_HIST = 5, 6, 7, 8
+STREAM_INIT_Z, STREAM_INIT_X, STREAM_UFINAL = 9, 10, 11
+
+
+class CsError(RuntimeError):
+    pass
+
+
+class cs_mlp_desc(C.Structure):
+    _fields_ = [("in_dim", C.c_int32), ("out_dim", C.c_int32), ("num_blocks", C.c_int32),
+                ("hidden", C.c_int32), ("out_split", C.c_int32)]
+
+
+class cs_rng(C.Structure):
+    _fields_ = [("seed", C.c_uint64), ("iteration", C.c_uint32), ("example_offset", C.c_int64)]
+
+
+class cs_lair_cfg(C.Structure):
+    _fields_ = [("B", C.c_int32), ("K", C.c_int32), ("R", C.c_int32), ("I", C.c_int32),
+                ("D", C.c_int32), ("Zd", C.c_int32), ("latent_dist", C.c_int32),
+                ("gen_dist", C.c_int32), ("weighting", C.c_int32), ("scheme", C.c_int32),
+                ("method", C.c_int32), ("cluster_size", C.c_int32), ("weight_alpha", C.c_float)]
+
+
+_LAIR_BUF_FIELDS = ["X", "M", "eps_z", "u_res", "u_res2", "u_sys", "u_sys2", "eps_x", "q", "Z", "gen",
+                    "gen_ll", "log_w", "norm_log_w", "idx", "ess", "tess", "perplexity",
+                    "latents_resampled", "idx2", "clip_min", "clip_max"]
+
+
+class cs_lair_bufs(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in _LAIR_BUF_FIELDS]
+
+
+_lib = None
+
+
+def lib():
+    """Load the HIP library (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise CsError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                      "(or `make -C vae_conditional_sampling_amd/csrc`). There is no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    L.cs_last_error.restype = C.c_char_p
+    L.cs_version.restype = C.c_int
+    vp, i64, u32, i32 = C.c_void_p, C.c_int64, C.c_uint32, C.c_int32
+    L.cs_mlp_create.argtypes = [C.POINTER(cs_mlp_desc), vp, vp, vp, vp, vp, vp, C.POINTER(vp)]
+    L.cs_mlp_destroy.argtypes = [vp]
+    L.cs_mlp_forward.argtypes = [vp, vp, i64, vp, vp]
+    L.cs_lair_encode.argtypes = [vp, C.POINTER(cs_lair_cfg), C.POINTER(cs_lair_bufs), vp]
+    L.cs_lair_decode.argtypes = [vp, C.POINTER(cs_lair_cfg), C.POINTER(cs_lair_bufs), C.POINTER(cs_rng), vp]
+    L.cs_lair_resample_impute.argtypes = [C.POINTER(cs_lair_cfg), C.POINTER(cs_lair_bufs), C.POINTER(cs_rng), vp]
+    L.cs_lair_step.argtypes = [vp, vp, C.POINTER(cs_lair_cfg), C.POINTER(cs_lair_bufs), C.POINTER(cs_rng), vp]
+    L.cs_decode_params.argtypes = [vp, vp, i64, i32, vp, vp]
+    L.cs_sample_impute.argtypes = [vp, i32, vp, C.POINTER(cs_rng), u32, vp, vp, i64, i32, i32, vp, vp, i32, vp]
+    for fn in ("cs_rng_normal", "cs_rng_uniform", "cs_rng_uniform64"):
+        getattr(L, fn).argtypes = [C.POINTER(cs_rng), u32, i64, i32, vp, vp]
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != 0:
+        raise CsError(f"libcsvae error {rc}: {lib().cs_last_error().decode()}")
+
+
+def current_stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    """Device pointer of a contiguous CUDA tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise CsError("libcsvae operates on device tensors only (no CPU path)")
+    if not t.is_contiguous():
+        raise CsError("tensor must be contiguous")
+    return t.data_ptr()
+
+
+def make_rng(seed, iteration=0, example_offset=0):
+    return cs_rng(int(seed) & 0xFFFFFFFFFFFFFFFF, int(iteration) & 0xFFFFFFFF, int(example_offset))
+
+
+def make_bufs(**tensors):
+    b = cs_lair_bufs()
+    for k, v in tensors.items():
+        if k not in _LAIR_BUF_FIELDS:
+            raise KeyError(k)
+        setattr(b, k, ptr(v))
+    return b
+
+
+class PackedMLP:
+    """Device handle of a residual MLP packed for the fused MFMA kernel (cs_mlp_create)."""
+
+    def __init__(self, W0, b0, blocks, Wf, bf, out_split):
+        L = lib()
+        if not torch.cuda.is_available():
+            raise CsError("no GPU visible: libcsvae has no CPU path")
+        f = lambda t: t.detach().to("cpu", torch.float32).contiguous()
+        W0, b0, Wf, bf = f(W0), f(b0), f(Wf), f(bf)
+        H, in_dim = W0.shape
+        out_dim = Wf.shape[0]
+        nb = len(blocks)
+        if nb:
+            Wb = torch.stack([torch.stack([f(W1), f(W2)]) for (W1, b1, W2, b2) in blocks]).contiguous()
+            bb = torch.stack([torch.stack([f(b1), f(b2)]) for (W1, b1, W2, b2) in blocks]).contiguous()
+        else:
+            Wb = torch.zeros(1); bb = torch.zeros(1)
+        self.desc = cs_mlp_desc(in_dim, out_dim, nb, H, out_split)
+        self.in_dim, self.out_dim, self.hidden, self.num_blocks = in_dim, out_dim, H, nb
+        h = C.c_void_p()
+        check(L.cs_mlp_create(C.byref(self.desc), W0.data_ptr(), b0.data_ptr(), Wb.data_ptr(), bb.data_ptr(),
+                              Wf.data_ptr(), bf.data_ptr(), C.byref(h)))
+        self.handle = h
+
+    def forward(self, x):
+        shape = x.shape
+        x2 = x.reshape(-1, shape[-1]).contiguous().float()
+        y = torch.empty(x2.shape[0], self.out_dim, device=x.device, dtype=torch.float32)
+        check(lib().cs_mlp_forward(self.handle, ptr(x2), x2.shape[0], ptr(y), current_stream()))
+        return y.reshape(*shape[:-1], self.out_dim)
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None) is not None and _lib is not None:
+                _lib.cs_mlp_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass

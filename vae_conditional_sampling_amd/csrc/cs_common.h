@@ -1,0 +1,131 @@
+// Shared device/host helpers for the conditional-sampling HIP library (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+
+#include "../../include/csvae.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define CS_LOG_SQRT_2PI 0.91893853320467274178f
+
+// ---- error reporting ---------------------------------------------------------------
+void cs_set_error(const std::string& msg);
+int cs_fail(int code, const std::string& msg);
+#define CS_HIP(call)                                                                      \
+  do {                                                                                    \
+    hipError_t e__ = (call);                                                              \
+    if (e__ != hipSuccess)                                                                \
+      return cs_fail(CS_EHIP, std::string(#call) + ": " + hipGetErrorString(e__));        \
+  } while (0)
+#define CS_REQUIRE(cond, msg)                                                             \
+  do {                                                                                    \
+    if (!(cond)) return cs_fail(CS_EINVAL, std::string(msg) + " [" #cond "]");            \
+  } while (0)
+
+// ---- Philox4x32-10 counter RNG -----------------------------------------------------
+// Draws are a pure function of (seed, stream, iteration, global row, element), so results do
+// not depend on how examples are batched or sharded over GPUs.
+struct CsPhilox {
+  uint32_t seed_lo, seed_hi;
+  uint32_t iter;       // sampler iteration
+  int64_t row_offset;  // added to the local example index (rank shard offset)
+};
+
+enum CsStream : uint32_t {
+  CS_STREAM_Z = 1,        // latent proposal noise, one row per (i, example, proposal)
+  CS_STREAM_X = 2,        // imputation noise, one row per (example, chain)
+  CS_STREAM_URES = 3,     // resampling uniforms, one row per example
+  CS_STREAM_URES2 = 4,    // second resampling (resampled latents)
+  CS_STREAM_ZPRIOR = 5,   // AC-MWG prior proposal
+  CS_STREAM_UPRIOR = 6,   // AC-MWG prior-mixture Bernoulli
+  CS_STREAM_UACC = 7,     // AC-MWG accept uniform
+  CS_STREAM_HIST = 8,     // AC-MWG history index
+  CS_STREAM_INIT_Z = 9,   // initial imputation latent
+  CS_STREAM_INIT_X = 10,  // initial imputation noise
+  CS_STREAM_UFINAL = 11,  // final resampling uniforms
+};
+
+__host__ __device__ inline void cs_philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                              uint32_t k0, uint32_t k1, uint32_t out[4]) {
+  const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    uint64_t p0 = (uint64_t)M0 * c0, p1 = (uint64_t)M1 * c2;
+    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    uint32_t n1 = (uint32_t)p1;
+    uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    uint32_t n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += W0; k1 += W1;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// Block `blk` of the draw sequence of (stream, row): 4 x uint32.
+__host__ __device__ inline void cs_philox_block(const CsPhilox& p, uint32_t stream, int64_t row,
+                                                uint32_t blk, uint32_t out[4]) {
+  uint64_t r = (uint64_t)(row);
+  cs_philox4x32(blk, (uint32_t)r, (uint32_t)(r >> 32) ^ (stream << 24), p.iter, p.seed_lo,
+                p.seed_hi, out);
+}
+
+// uint32 -> float uniform in (0,1): 24 mantissa bits, never 0 or 1.
+__host__ __device__ inline float cs_u01f(uint32_t x) {
+  return (float)(x >> 8) * 5.9604644775390625e-08f + 2.98023223876953125e-08f;
+}
+// 2 x uint32 -> double uniform in [0,1) with 53 bits.
+__host__ __device__ inline double cs_u01d(uint32_t hi, uint32_t lo) {
+  uint64_t v = (((uint64_t)hi << 32) | lo) >> 11;
+  return (double)v * 1.1102230246251565e-16;
+}
+
+struct CsPhilox cs_make_philox(const cs_rng* r);
+
+#ifdef __HIPCC__
+// 4 standard normals from one Philox block (two Box-Muller pairs).
+__device__ inline f32x4 cs_normal4(const uint32_t x[4]) {
+  float r0 = sqrtf(-2.0f * logf(cs_u01f(x[0])));
+  float r1 = sqrtf(-2.0f * logf(cs_u01f(x[2])));
+  float s0, c0, s1, c1;
+  sincosf(6.283185307179586f * cs_u01f(x[1]), &s0, &c0);
+  sincosf(6.283185307179586f * cs_u01f(x[3]), &s1, &c1);
+  f32x4 n;
+  n.x = r0 * c0; n.y = r0 * s0; n.z = r1 * c1; n.w = r1 * s1;
+  return n;
+}
+// Element `e` of the standard-normal sequence of (stream,row).
+__device__ inline float cs_normal_elem(const CsPhilox& p, uint32_t stream, int64_t row, uint32_t e) {
+  uint32_t x[4];
+  cs_philox_block(p, stream, row, e >> 2, x);
+  f32x4 n = cs_normal4(x);
+  uint32_t c = e & 3u;
+  return c == 0 ? n.x : (c == 1 ? n.y : (c == 2 ? n.z : n.w));
+}
+__device__ inline float cs_uniform_elem(const CsPhilox& p, uint32_t stream, int64_t row, uint32_t e) {
+  uint32_t x[4];
+  cs_philox_block(p, stream, row, e >> 2, x);
+  return cs_u01f(x[e & 3u]);
+}
+__device__ inline double cs_uniform64_elem(const CsPhilox& p, uint32_t stream, int64_t row, uint32_t e) {
+  uint32_t x[4];
+  cs_philox_block(p, stream, row, e >> 1, x);
+  return (e & 1u) ? cs_u01d(x[2], x[3]) : cs_u01d(x[0], x[1]);
+}
+
+// torch.nn.functional.softplus (beta 1, threshold 20).
+__device__ inline float cs_softplus(float x) { return x > 20.0f ? x : log1pf(expf(x)); }
+// torch.distributions.Normal.log_prob with the operation order of the reference's torch.
+__device__ inline float cs_normal_logpdf(float x, float loc, float scale) {
+  float d = x - loc;
+  return -(d * d) / (2.0f * (scale * scale)) - logf(scale) - CS_LOG_SQRT_2PI;
+}
+__device__ inline float cs_stdnormal_logpdf(float z) { return -(z * z) / 2.0f - CS_LOG_SQRT_2PI; }
+// -BCEWithLogits(l, x) = x*l - softplus(l), in torch's stable form.
+__device__ inline float cs_bernoulli_logpmf(float x, float l) {
+  return -((1.0f - x) * l + fmaxf(-l, 0.0f) + log1pf(expf(-fabsf(l))));
+}
+__device__ inline float cs_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+#endif

@@ -1,0 +1,455 @@
+// LAIR iteration stages (importance_resampling_gibbs_iteration,
+// irwg/sampling/vae_imputation.py:484-726) on top of the fused MLP kernel:
+//   cs_lair_encode           encoder + proposal parameterisation           (:551, vae.py:214-219)
+//   cs_lair_decode           Z sampling + decoder + masked log-likelihood  (:596-603, weights.py:46-47)
+//   cs_lair_resample_impute  DM-MIS weights, resampling, x_m sampling, in-place imputation,
+//                            ESS / perplexity   (weights.py:50-85; vae_imputation.py:284-308,
+//                            335-378, 380-458, 677-726, 804-834)
+#include "cs_mlp.h"
+
+#include <cstring>
+
+// ----------------------------------------------------------------------------------------
+// One wavefront per example.  Lane s < S = I*K' owns proposal s = i*K' + k'.
+// Proposals are partitioned in G groups of c members per importance sample (gr: G = 1,
+// c = K'; glr: member k' belongs to group k' mod G, '(c k)' layout of the reference); the
+// deterministic-mixture proposal density and the resampling are both "within group" when the
+// corresponding option asks for it.
+// ----------------------------------------------------------------------------------------
+struct CsResampleArgs {
+  cs_lair_cfg cfg;
+  cs_lair_bufs b;
+  CsPhilox rng;
+  int Kp, S, G, c;       // resampling groups
+  int mixG, mixc;        // mixture groups (dmis: 1,K'; within groups: G,c; smis: K',1)
+  int lds_per_wave;      // floats
+};
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+// torch.logsumexp over the lanes with `in` set (others ignored): max, masked to 0 when not
+// finite, log(sum(exp(x - max))) + max.
+__device__ __forceinline__ float wave_logsumexp(float x, bool in) {
+  float m = wave_max(in ? x : -INFINITY);
+  if (!(fabsf(m) < INFINITY)) m = 0.0f;
+  const float s = wave_sum(in ? expf(x - m) : 0.0f);
+  return logf(s) + m;
+}
+
+__global__ void __launch_bounds__(256) cs_lair_resample_kernel(const CsResampleArgs a) {
+  extern __shared__ float lds_all[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t b = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave;
+  const bool valid = b < a.cfg.B;
+  const int B = a.cfg.B, K = a.cfg.K, D = a.cfg.D, Zd = a.cfg.Zd, I = a.cfg.I;
+  const int Kp = a.Kp, S = a.S, G = a.G, c = a.c;
+  float* lds = lds_all + (size_t)wave * a.lds_per_wave;
+  float* l_loc = lds;                 // [Kp*Zd]
+  float* l_2var = l_loc + Kp * Zd;    // [Kp*Zd]  2*scale^2
+  float* l_logs = l_2var + Kp * Zd;   // [Kp*Zd]  log(scale)
+  float* l_z = l_logs + Kp * Zd;      // [S*(Zd+1)]
+  int* l_idx = (int*)(l_z + S * (Zd + 1));  // [2*Kp] resampled global indices (two draws)
+
+  if (valid) {
+    const float* qb = a.b.q + b * Kp * 2 * Zd;
+    for (int t = lane; t < Kp * Zd; t += 64) {
+      const int j = t / Zd, d = t - j * Zd;
+      const float loc = qb[j * 2 * Zd + d], sc = qb[j * 2 * Zd + Zd + d];
+      l_loc[t] = loc;
+      l_2var[t] = 2.0f * (sc * sc);
+      l_logs[t] = logf(sc);
+    }
+    for (int t = lane; t < S * Zd; t += 64) {
+      const int s = t / Zd, d = t - s * Zd;
+      const int i = s / Kp, kp = s - i * Kp;
+      l_z[s * (Zd + 1) + d] = a.b.Z[(((int64_t)i * B + b) * Kp + kp) * Zd + d];
+    }
+  }
+  __syncthreads();
+
+  const bool act = valid && lane < S;
+  const int s = lane;
+  const int i_s = act ? s / Kp : 0, kp_s = act ? s - i_s * Kp : 0;
+  float lw = -INFINITY;
+  if (act) {
+    const float* z = l_z + s * (Zd + 1);
+    float pl = 0.0f;
+    for (int d = 0; d < Zd; ++d) pl += cs_stdnormal_logpdf(z[d]);
+    // mixture components of this proposal: j = gm + mixG*cc, cc < mixc
+    const int gm = kp_s % a.mixG;
+    float ql;
+    if (a.cfg.weighting == CS_W_SMIS) {
+      float cj = 0.0f;
+      for (int d = 0; d < Zd; ++d) {
+        const float df = z[d] - l_loc[kp_s * Zd + d];
+        cj += -(df * df) / l_2var[kp_s * Zd + d] - l_logs[kp_s * Zd + d] - CS_LOG_SQRT_2PI;
+      }
+      ql = cj;
+    } else {
+      float m = -INFINITY;
+      for (int cc = 0; cc < a.mixc; ++cc) {
+        const int j = gm + a.mixG * cc;
+        float cj = 0.0f;
+        for (int d = 0; d < Zd; ++d) {
+          const float df = z[d] - l_loc[j * Zd + d];
+          cj += -(df * df) / l_2var[j * Zd + d] - l_logs[j * Zd + d] - CS_LOG_SQRT_2PI;
+        }
+        m = fmaxf(m, cj);
+      }
+      if (!(fabsf(m) < INFINITY)) m = 0.0f;
+      float sum = 0.0f;
+      for (int cc = 0; cc < a.mixc; ++cc) {
+        const int j = gm + a.mixG * cc;
+        float cj = 0.0f;
+        for (int d = 0; d < Zd; ++d) {
+          const float df = z[d] - l_loc[j * Zd + d];
+          cj += -(df * df) / l_2var[j * Zd + d] - l_logs[j * Zd + d] - CS_LOG_SQRT_2PI;
+        }
+        sum += expf(cj - m);
+      }
+      ql = logf(sum) + m - logf((float)a.mixc);
+    }
+    const int64_t rho = ((int64_t)i_s * B + b) * Kp + kp_s;
+    lw = a.b.gen_ll[rho] + pl - ql;
+    a.b.log_w[rho] = lw;
+  }
+  const float tlw = (a.cfg.weight_alpha == 1.0f) ? lw : lw * a.cfg.weight_alpha;
+
+  // ---- ESS / perplexity over all S proposals (vae_imputation.py:708-719) ----
+  {
+    const float lse = wave_logsumexp(lw, act);
+    const float lnw = lw - lse;
+    const float ess = expf(-wave_logsumexp(2.0f * lnw, act));
+    const float perp = expf(-wave_sum(act ? lnw * expf(lnw) : 0.0f));
+    float tess = ess;
+    if (a.cfg.weight_alpha != 1.0f) {
+      const float tl = tlw - wave_logsumexp(tlw, act);
+      tess = expf(-wave_logsumexp(2.0f * tl, act));
+    }
+    if (valid && lane == 0) {
+      a.b.ess[b] = ess;
+      a.b.tess[b] = tess;
+      a.b.perplexity[b] = perp;
+    }
+  }
+
+  // ---- resampling within groups ----
+  const int g_s = kp_s % G, cc_s = kp_s / G;
+  const int li_s = i_s * c + cc_s;  // position inside the group, '(i c)' order
+  // group log-normaliser
+  float lse_g = 0.0f;
+  for (int g = 0; g < G; ++g) {
+    const float v = wave_logsumexp(tlw, act && g_s == g);
+    if (g_s == g) lse_g = v;
+  }
+  const float nl = tlw - lse_g;  // normalised log-weight (Categorical.logits)
+  if (act) a.b.norm_log_w[b * S + (int64_t)g_s * (I * c) + li_s] = nl;
+
+  float p;
+  if (a.cfg.method == CS_RM_MULTINOMIAL) {
+    // Categorical.probs = softmax(normalised logits)
+    float mx = 0.0f, sm = 1.0f;
+    for (int g = 0; g < G; ++g) {
+      const bool in = act && g_s == g;
+      const float m = wave_max(in ? nl : -INFINITY);
+      const float su = wave_sum(in ? expf(nl - m) : 0.0f);
+      if (g_s == g) { mx = m; sm = su; }
+    }
+    p = act ? expf(nl - mx) / sm : 0.0f;
+  } else {
+    // systematic: exp(normalised log-weights), renormalised by their sum (:813-817)
+    float sm = 1.0f;
+    const float e = act ? expf(nl) : 0.0f;
+    for (int g = 0; g < G; ++g) {
+      const float su = wave_sum((act && g_s == g) ? e : 0.0f);
+      if (g_s == g) sm = su;
+    }
+    p = e / sm;
+  }
+  // sequential float32 running sum inside each group, in member order
+  float run = 0.0f, cum = 0.0f;
+  for (int jj = 0; jj < S; ++jj) {
+    const float pj = __shfl(p, jj);
+    const int gj = (jj % Kp) % G;
+    if (gj == g_s) run += pj;
+    if (lane == jj) cum = run;
+  }
+  const bool last_in_group = act && (i_s == I - 1) && (cc_s == c - 1);
+
+  const int ndraw_sets = (a.b.latents_resampled != nullptr) ? 2 : 1;
+  for (int set = 0; set < ndraw_sets; ++set) {
+    if (a.cfg.method == CS_RM_MULTINOMIAL) {
+      // torch.multinomial: cum / total, last forced to 1, left bisection with float64 uniforms
+      float cn = cum / run;
+      if (last_in_group) cn = 1.0f;
+      const double* uin = set == 0 ? a.b.u_res : a.b.u_res2;
+      for (int g = 0; g < G; ++g) {
+        for (int t = 0; t < c; ++t) {
+          double u;
+          if (uin) u = valid ? uin[(b * G + g) * c + t] : 0.0;
+          else u = cs_uniform64_elem(a.rng, set == 0 ? CS_STREAM_URES : CS_STREAM_URES2, a.rng.row_offset + b,
+                                     (uint32_t)(g * c + t));
+          const unsigned long long mask = __ballot(act && g_s == g && (double)cn < u);
+          int li = __popcll(mask);
+          if (li > I * c - 1) li = I * c - 1;
+          const int il = li / c, cl = li - il * c;
+          if (lane == 0) l_idx[set * Kp + t * G + g] = il * Kp + cl * G + g;
+        }
+      }
+    } else {
+      const float* uin = set == 0 ? a.b.u_sys : a.b.u_sys2;
+      // n = clamp(floor(cumsum(p)*m + U), 0, m); index[t] = #{members : n <= t}
+      float U = 0.0f;
+      for (int g = 0; g < G; ++g) {
+        float ug;
+        if (uin) ug = valid ? uin[b * G + g] : 0.0f;
+        else ug = cs_uniform_elem(a.rng, set == 0 ? CS_STREAM_URES : CS_STREAM_URES2, a.rng.row_offset + b, (uint32_t)g);
+        if (g_s == g) U = ug;
+      }
+      float nf = floorf(cum * (float)c + U);
+      nf = fminf(fmaxf(nf, 0.0f), (float)c);
+      const int n = (int)nf;
+      for (int g = 0; g < G; ++g) {
+        for (int t = 0; t < c; ++t) {
+          const unsigned long long mask = __ballot(act && g_s == g && n <= t);
+          int li = __popcll(mask);
+          if (li > I * c - 1) li = I * c - 1;  // the reference would index out of bounds here
+          const int il = li / c, cl = li - il * c;
+          if (lane == 0) l_idx[set * Kp + t * G + g] = il * Kp + cl * G + g;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (valid && lane < Kp) {
+    a.b.idx[b * Kp + lane] = l_idx[lane];
+    if (ndraw_sets == 2 && a.b.idx2) a.b.idx2[b * Kp + lane] = l_idx[Kp + lane];
+  }
+  if (!valid) return;
+
+  // ---- resampled latents (second, independent draw; vae_imputation.py:649-650) ----
+  if (ndraw_sets == 2) {
+    for (int t = lane; t < Kp * Zd; t += 64) {
+      const int n = t / Zd, d = t - n * Zd;
+      a.b.latents_resampled[b * Kp * Zd + t] = l_z[l_idx[Kp + n] * (Zd + 1) + d];
+    }
+  }
+
+  // ---- sample the missing values from the resampled generator parameters and impute ----
+  const uint8_t* mr = a.b.M + b * D;
+  for (int n = 0; n < K; ++n) {
+    const int src = l_idx[n];
+    const int i = src / Kp, kp = src - i * Kp;
+    const int64_t rho = ((int64_t)i * B + b) * Kp + kp;
+    float* xr = a.b.X + (b * K + n) * D;
+    const int64_t xrow = (a.rng.row_offset + b) * K + n;
+    for (int d = lane; d < D; d += 64) {
+      float xm;
+      if (a.cfg.gen_dist == CS_DIST_BERN) {
+        const float u = a.b.eps_x ? a.b.eps_x[(b * K + n) * D + d] : cs_uniform_elem(a.rng, CS_STREAM_X, xrow, d);
+        xm = (u < cs_sigmoid(a.b.gen[rho * D + d])) ? 1.0f : 0.0f;
+      } else {
+        const float e = a.b.eps_x ? a.b.eps_x[(b * K + n) * D + d] : cs_normal_elem(a.rng, CS_STREAM_X, xrow, d);
+        xm = a.b.gen[rho * 2 * D + d] + a.b.gen[rho * 2 * D + D + d] * e;
+      }
+      const float xo = xr[d];
+      const float m = (float)mr[d];
+      float xn = xo * m + xm * (1.0f - m);
+      if (a.b.clip_min) xn = (xn != xn) ? xn : fmaxf(xn, a.b.clip_min[d]);
+      if (a.b.clip_max) xn = (xn != xn) ? xn : fminf(xn, a.b.clip_max[d]);
+      if ((a.b.clip_min || a.b.clip_max) && !(fabsf(xn) < INFINITY)) xn = xo;
+      xr[d] = xn;
+    }
+  }
+}
+
+// ----------------------------------------------------------------------------------------
+static int check_cfg(const cs_lair_cfg* c, const cs_lair_bufs* b) {
+  CS_REQUIRE(c && b, "null argument");
+  CS_REQUIRE(c->B >= 0 && c->K >= 1 && c->R >= 0 && c->I >= 1 && c->D >= 1 && c->Zd >= 1, "bad sizes");
+  CS_REQUIRE(c->latent_dist == CS_DIST_NORMAL || c->latent_dist == CS_DIST_NORMAL_WITH_EPS,
+             "latent distribution must be normal / normal_with_eps");
+  CS_REQUIRE(c->gen_dist >= CS_DIST_NORMAL && c->gen_dist <= CS_DIST_BERN, "bad generator distribution");
+  return CS_OK;
+}
+
+extern "C" int cs_lair_encode(const cs_mlp_t* enc, const cs_lair_cfg* c, const cs_lair_bufs* b, void* stream) {
+  if (int rc = check_cfg(c, b)) return rc;
+  CS_REQUIRE(enc && b->X && b->q, "null argument");
+  CS_REQUIRE(enc->dev.in_dim == c->D && enc->dev.out_dim == 2 * c->Zd && enc->dev.split == 2,
+             "encoder shape does not match the configuration");
+  CsMlpArgs a;
+  std::memset(&a, 0, sizeof(a));
+  a.net = enc->dev;
+  a.mode = CS_MLP_ENC;
+  a.rows = (int64_t)c->B * c->K;
+  a.in = b->X;
+  a.in_stride = c->D;
+  a.q = b->q;
+  a.K = c->K; a.Kp = c->K + c->R; a.Zd = c->Zd; a.B = c->B; a.I = c->I; a.D = c->D;
+  a.latent_eps = c->latent_dist == CS_DIST_NORMAL_WITH_EPS;
+  return cs_mlp_launch(a, (hipStream_t)stream);
+}
+
+extern "C" int cs_lair_decode(const cs_mlp_t* dec, const cs_lair_cfg* c, const cs_lair_bufs* b, const cs_rng* rng,
+                              void* stream) {
+  if (int rc = check_cfg(c, b)) return rc;
+  CS_REQUIRE(dec && b->X && b->M && b->q && b->Z && b->gen && b->gen_ll, "null argument");
+  const bool bern = c->gen_dist == CS_DIST_BERN;
+  CS_REQUIRE(dec->dev.in_dim == c->Zd && dec->dev.out_dim == (bern ? 1 : 2) * c->D &&
+                 dec->dev.split == (bern ? 1 : 2),
+             "decoder shape does not match the configuration");
+  CsMlpArgs a;
+  std::memset(&a, 0, sizeof(a));
+  a.net = dec->dev;
+  a.mode = CS_MLP_DEC;
+  a.K = c->K; a.Kp = c->K + c->R; a.Zd = c->Zd; a.B = c->B; a.I = c->I; a.D = c->D;
+  a.rows = (int64_t)c->I * c->B * a.Kp;
+  a.q = b->q;
+  a.gen_dist = c->gen_dist;
+  a.eps_z = b->eps_z;
+  a.rng = cs_make_philox(rng);
+  a.Z = b->Z;
+  a.gen = b->gen;
+  a.gen_ll = b->gen_ll;
+  a.X = b->X;
+  a.M = b->M;
+  return cs_mlp_launch(a, (hipStream_t)stream);
+}
+
+extern "C" int cs_lair_resample_impute(const cs_lair_cfg* c, const cs_lair_bufs* b, const cs_rng* rng, void* stream) {
+  if (int rc = check_cfg(c, b)) return rc;
+  CS_REQUIRE(b->X && b->M && b->q && b->Z && b->gen && b->gen_ll && b->log_w && b->norm_log_w && b->idx &&
+                 b->ess && b->tess && b->perplexity,
+             "null argument");
+  CsResampleArgs a;
+  std::memset(&a, 0, sizeof(a));
+  a.cfg = *c;
+  a.b = *b;
+  a.rng = cs_make_philox(rng);
+  a.Kp = c->K + c->R;
+  a.S = c->I * a.Kp;
+  CS_REQUIRE(a.S <= 64, "I*(K+R) must be <= 64");
+  if (c->scheme == CS_RS_GR) {
+    a.G = 1; a.c = a.Kp;
+  } else if (c->scheme == CS_RS_GLR) {
+    CS_REQUIRE(c->cluster_size > 1 && a.Kp % c->cluster_size == 0, "glr needs cluster_size > 1 dividing K+R");
+    a.c = c->cluster_size; a.G = a.Kp / a.c;
+  } else {
+    return cs_fail(CS_EUNSUPPORTED, "resampling scheme not implemented (gr, glr only)");
+  }
+  if (c->weighting == CS_W_DMIS) {
+    a.mixG = 1; a.mixc = a.Kp;
+  } else if (c->weighting == CS_W_DMIS_WITHIN_GROUPS) {
+    CS_REQUIRE(c->cluster_size > 1 && a.Kp % c->cluster_size == 0, "grouped weights need cluster_size > 1 dividing K+R");
+    a.mixc = c->cluster_size; a.mixG = a.Kp / a.mixc;
+  } else if (c->weighting == CS_W_SMIS) {
+    a.mixG = a.Kp; a.mixc = 1;
+  } else {
+    return cs_fail(CS_EUNSUPPORTED, "weighting scheme not implemented");
+  }
+  CS_REQUIRE(c->method == CS_RM_MULTINOMIAL || c->method == CS_RM_SYSTEMATIC, "bad resampling method");
+  if (c->B == 0) return CS_OK;
+  a.lds_per_wave = 3 * a.Kp * c->Zd + a.S * (c->Zd + 1) + 2 * a.Kp;
+  a.lds_per_wave = (a.lds_per_wave + 3) & ~3;
+  int waves = 4;
+  while (waves > 1 && (size_t)waves * a.lds_per_wave * 4 > 60 * 1024) waves >>= 1;
+  CS_REQUIRE((size_t)waves * a.lds_per_wave * 4 <= 64 * 1024, "proposal set too large for the LDS working set");
+  const unsigned grid = (unsigned)((c->B + waves - 1) / waves);
+  hipLaunchKernelGGL(cs_lair_resample_kernel, dim3(grid), dim3(64 * waves), (size_t)waves * a.lds_per_wave * 4,
+                     (hipStream_t)stream, a);
+  CS_HIP(hipGetLastError());
+  return CS_OK;
+}
+
+extern "C" int cs_lair_step(const cs_mlp_t* enc, const cs_mlp_t* dec, const cs_lair_cfg* c, const cs_lair_bufs* b,
+                            const cs_rng* rng, void* stream) {
+  if (int rc = cs_lair_encode(enc, c, b, stream)) return rc;
+  if (int rc = cs_lair_decode(dec, c, b, rng, stream)) return rc;
+  return cs_lair_resample_impute(c, b, rng, stream);
+}
+
+// ----------------------------------------------------------------------------------------
+// Generator parameterisation of given latents, and sampling + imputation from generator
+// parameters: the x_m | z step of pseudo_gibbs_iteration (vae_imputation.py:28-45), of the
+// initial 'vae_samples' imputation (test_step_vae_sampling.py:279-287 with vae.py:166-178)
+// and of the final decode of LAIR (test_step_vae_sampling.py:2019-2026).
+// ----------------------------------------------------------------------------------------
+extern "C" int cs_decode_params(const cs_mlp_t* dec, const float* Z, int64_t rows, int32_t gen_dist, float* gen,
+                                void* stream) {
+  CS_REQUIRE(dec && Z && gen && rows >= 0, "bad argument");
+  const bool bern = gen_dist == CS_DIST_BERN;
+  CS_REQUIRE(dec->dev.split == (bern ? 1 : 2), "decoder output split does not match the distribution");
+  CsMlpArgs a;
+  std::memset(&a, 0, sizeof(a));
+  a.net = dec->dev;
+  a.mode = CS_MLP_DEC;
+  a.rows = rows;
+  a.in = Z;
+  a.in_stride = dec->dev.in_dim;
+  a.K = 1; a.Kp = 1; a.B = 1; a.I = 1;
+  a.Zd = dec->dev.in_dim;
+  a.D = dec->dev.out_dim / dec->dev.split;
+  a.gen_dist = gen_dist;
+  a.gen = gen;
+  return cs_mlp_launch(a, (hipStream_t)stream);
+}
+
+struct CsSampleImputeArgs {
+  const float* gen; int gen_dist; const float* eps; CsPhilox rng; uint32_t stream_id;
+  float* X; const uint8_t* M; int64_t rows; int K, D; const float* clip_min; const float* clip_max;
+  int flags;
+};
+
+__global__ void __launch_bounds__(256) cs_sample_impute_kernel(const CsSampleImputeArgs a) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= a.rows * a.D) return;
+  const int64_t row = t / a.D;
+  const int d = (int)(t - row * a.D);
+  const int64_t b = row / a.K;
+  float xm;
+  if (a.gen_dist == CS_DIST_BERN) {
+    const float u = a.eps ? a.eps[t] : cs_uniform_elem(a.rng, a.stream_id, a.rng.row_offset * a.K + row, d);
+    xm = (u < cs_sigmoid(a.gen[t])) ? 1.0f : 0.0f;
+  } else {
+    const float e = a.eps ? a.eps[t] : cs_normal_elem(a.rng, a.stream_id, a.rng.row_offset * a.K + row, d);
+    xm = a.gen[row * 2 * a.D + d] + a.gen[row * 2 * a.D + a.D + d] * e;
+  }
+  // pseudo-Gibbs safety (vae_imputation.py:34-41): clip the sample, keep the old value where
+  // the sample is not finite; then blend
+  if (a.clip_min) xm = (xm != xm) ? xm : fmaxf(xm, a.clip_min[d]);
+  if (a.clip_max) xm = (xm != xm) ? xm : fminf(xm, a.clip_max[d]);
+  float xn = xm;
+  if (a.M) {
+    const float m = (float)a.M[b * a.D + d];
+    float xo = a.X[t];
+    if ((a.flags & 1) && m == 0.0f) xo = 0.0f;
+    if ((a.flags & 2) && !(fabsf(xm) < INFINITY)) xm = xo;
+    xn = xo * m + xm * (1.0f - m);
+  }
+  a.X[t] = xn;
+}
+
+extern "C" int cs_sample_impute(const float* gen, int32_t gen_dist, const float* eps, const cs_rng* rng,
+                                uint32_t stream_id, float* X, const uint8_t* M, int64_t B, int32_t K, int32_t D,
+                                const float* clip_min, const float* clip_max, int32_t flags, void* stream) {
+  CS_REQUIRE(gen && X && B >= 0 && K >= 1 && D >= 1, "bad argument");
+  CS_REQUIRE(gen_dist >= CS_DIST_NORMAL && gen_dist <= CS_DIST_BERN, "bad generator distribution");
+  if (B == 0) return CS_OK;
+  CsSampleImputeArgs a;
+  a.gen = gen; a.gen_dist = gen_dist; a.eps = eps; a.rng = cs_make_philox(rng); a.stream_id = stream_id;
+  a.X = X; a.M = M; a.rows = B * K; a.K = K; a.D = D; a.clip_min = clip_min; a.clip_max = clip_max;
+  a.flags = flags;
+  const int64_t n = a.rows * D;
+  hipLaunchKernelGGL(cs_sample_impute_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+  CS_HIP(hipGetLastError());
+  return CS_OK;
+}

@@ -1,0 +1,59 @@
+// Fused whole-network residual-MLP kernel (exact-f32 MFMA) -- internal interface.
+#pragma once
+#include "cs_common.h"
+
+// Device-side description of a packed network.
+struct CsMlpDev {
+  const f32x4* wstream;  // packed MFMA A-operand stream (see cs_mlp.hip)
+  const float* bias;     // [2*nb+2][bias_stride], final layer in tile order
+  int nb;                // residual blocks
+  int nkt0;              // first-layer k-tiles = ceil(in_dim/32)
+  int in_dim, out_dim;
+  int out_half;          // out_dim / out_split
+  int tph;               // output tiles per half = ceil(out_half/32)
+  int nt;                // hidden/32
+  int nto;               // output tiles = out_split*tph
+  int split;
+  int bias_stride;
+};
+
+struct cs_mlp {
+  cs_mlp_desc desc;
+  CsMlpDev dev;
+  void* d_w;
+  void* d_b;
+  int device;
+};
+
+enum CsMlpMode : int { CS_MLP_RAW = 0, CS_MLP_ENC = 1, CS_MLP_DEC = 2 };
+
+struct CsMlpArgs {
+  CsMlpDev net;
+  int mode;
+  int64_t rows;
+  // RAW / ENC input: row r at in + r*in_stride, or in + in_off[r] when in_off != nullptr
+  const float* in;
+  int64_t in_stride;
+  const int64_t* in_off;
+  // RAW output [rows,out_dim]
+  float* out;
+  // ENC: rows are (b,k), k < K; q[(b*Kp+k)*2*Zd + {0,Zd} + z]
+  // DEC: rows are (i,b,k'), k' < Kp
+  float* q;
+  int K, Kp, Zd, B, I, D;
+  int latent_eps;  // 1: scale += 1e-8
+  int gen_dist;    // CS_DIST_*
+  // DEC prologue
+  const float* eps_z;         // [rows,Zd] or nullptr -> Philox
+  const uint8_t* z_override;  // optional [rows]: 1 -> take Z from z_alt instead
+  const float* z_alt;         // [rows,Zd]
+  CsPhilox rng;
+  float* Z;                   // [rows,Zd] out
+  // DEC epilogue
+  float* gen;        // [rows,2,D] (normal) or [rows,D] (bern)
+  float* gen_ll;     // [rows]
+  const float* X;    // [B,K,D]
+  const uint8_t* M;  // [B,D]
+};
+
+int cs_mlp_launch(const CsMlpArgs& a, hipStream_t stream);

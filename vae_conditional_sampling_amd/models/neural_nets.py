@@ -1,0 +1,79 @@
+"""Residual MLP with the reference's constructor and state-dict layout, computed by the fused
+HIP kernel.
+
+Mirrors ``ResidualFCNetwork`` (irwg/models/neural_nets.py:106-169): parameters are registered
+under the same names (``initial_layer``, ``blocks.{i}.linear_layers.{0,1}``, ``final_layer``)
+so that the ``generator_network.*`` / ``var_latent_network.*`` entries of a Lightning
+checkpoint load unchanged.  ``forward`` packs the weights into the MFMA operand stream on
+first use (re-packed after ``load_state_dict`` / ``.to``) and calls ``cs_mlp_forward``.
+"""
+from typing import Callable, Union
+
+import torch
+import torch.nn as nn
+
+from .. import _lib
+
+
+class _Block(nn.Module):
+    def __init__(self, features):
+        super().__init__()
+        self.linear_layers = nn.ModuleList([nn.Linear(features, features) for _ in range(2)])
+
+
+class ResidualFCNetwork(nn.Module):
+    def __init__(self, input_dim: int, output_dim: int, num_residual_blocks: int, residual_block_dim: int, *,
+                 activation: Union[Callable, str] = "relu", dropout_probability: float = 0.0,
+                 use_batch_norm: bool = False, use_layer_norm: bool = False):
+        super().__init__()
+        if use_batch_norm or use_layer_norm:
+            raise NotImplementedError("normalisation layers inside residual blocks are not implemented")
+        if not (activation == "relu" or getattr(activation, "__name__", "") == "relu"):
+            raise NotImplementedError("only the ReLU activation is implemented")
+        self.input_dims = input_dim
+        self.output_dim = output_dim
+        self.num_residual_blocks = num_residual_blocks
+        self.residual_block_dim = residual_block_dim
+        self.dropout_probability = dropout_probability  # identity in eval mode
+        self.initial_layer = nn.Linear(input_dim, residual_block_dim)
+        self.blocks = nn.ModuleList([_Block(residual_block_dim) for _ in range(num_residual_blocks)])
+        self.final_layer = nn.Linear(residual_block_dim, output_dim)
+        self.out_split = 2  # (loc | raw scale); the VAE sets 1 for Bernoulli logits
+        self._packed = None
+        self._packed_key = None
+        self.requires_grad_(False)
+
+    @property
+    def input_dim(self):
+        return self.input_dims
+
+    def weight_dict(self):
+        blocks = [(b.linear_layers[0].weight, b.linear_layers[0].bias, b.linear_layers[1].weight,
+                   b.linear_layers[1].bias) for b in self.blocks]
+        return {"W0": self.initial_layer.weight, "b0": self.initial_layer.bias, "blocks": blocks,
+                "Wf": self.final_layer.weight, "bf": self.final_layer.bias}
+
+    def load_weight_dict(self, w):
+        with torch.no_grad():
+            self.initial_layer.weight.copy_(w["W0"]); self.initial_layer.bias.copy_(w["b0"])
+            for blk, (W1, b1, W2, b2) in zip(self.blocks, w["blocks"]):
+                blk.linear_layers[0].weight.copy_(W1); blk.linear_layers[0].bias.copy_(b1)
+                blk.linear_layers[1].weight.copy_(W2); blk.linear_layers[1].bias.copy_(b2)
+            self.final_layer.weight.copy_(w["Wf"]); self.final_layer.bias.copy_(w["bf"])
+        self._packed = None
+        return self
+
+    def packed(self):
+        """Device handle of the packed network (built lazily, rebuilt when weights change)."""
+        key = (tuple((p.data_ptr(), p._version) for p in self.parameters()), self.out_split,
+               torch.cuda.current_device())
+        if self._packed is None or self._packed_key != key:
+            w = self.weight_dict()
+            self._packed = _lib.PackedMLP(w["W0"], w["b0"], w["blocks"], w["Wf"], w["bf"], self.out_split)
+            self._packed_key = key
+        return self._packed
+
+    def forward(self, inputs: torch.Tensor):
+        if self.training:
+            raise NotImplementedError("training mode (dropout) is not implemented; call .eval()")
+        return self.packed().forward(inputs)

@@ -1,0 +1,159 @@
+"""Thin host layer between the reference-shaped Python API and the C ABI.
+
+Holds the per-shape device workspaces (so the sampler loop allocates nothing per
+iteration) and turns Python arguments into ``cs_lair_cfg`` / ``cs_lair_bufs`` structs.
+"""
+import ctypes as C
+
+import torch
+
+from .. import _lib
+
+
+def mask_u8(M):
+    """[B,1,D] / [B,D] bool mask -> contiguous uint8 [B,D] (1 = observed)."""
+    if M.dim() == 3:
+        M = M[:, 0]
+    return M.to(torch.uint8).contiguous()
+
+
+class LairWorkspace:
+    """Device buffers of one LAIR configuration (B, K, R, I)."""
+
+    def __init__(self, model, B, K, R, I, device):
+        self.B, self.K, self.R, self.I = B, K, R, I
+        self.Kp = K + R
+        self.D = model.generator_network.output_dim // (1 if model.hparams.generator_distribution.name == "bern" else 2)
+        self.Zd = model.latent_dim
+        self.P = model.generator_network.output_dim
+        f = dict(device=device, dtype=torch.float32)
+        Kp, Zd, D, P = self.Kp, self.Zd, self.D, self.P
+        self.q = torch.empty(B, Kp, 2, Zd, **f)
+        self.Z = torch.empty(I, B, Kp, Zd, **f)
+        self.gen = torch.empty(I, B, Kp, P, **f)
+        self.gen_ll = torch.empty(I, B, Kp, **f)
+        self.log_w = torch.empty(I, B, Kp, **f)
+        self.norm_log_w = torch.empty(B, I * Kp, **f)
+        self.idx = torch.empty(B, Kp, device=device, dtype=torch.int64)
+        self.stats = torch.empty(3, B, **f)  # ess, transformed ess, perplexity
+        self.latents_resampled = None
+        self.idx2 = None
+
+    def want_latents(self):
+        if self.latents_resampled is None:
+            self.latents_resampled = torch.empty(self.B, self.Kp, self.Zd, device=self.q.device, dtype=torch.float32)
+            self.idx2 = torch.empty(self.B, self.Kp, device=self.q.device, dtype=torch.int64)
+
+
+def lair_workspace(model, B, K, R, I, device):
+    cache = model.__dict__.setdefault("_cs_workspaces", {})
+    key = ("lair", B, K, R, I, str(device))
+    ws = cache.get(key)
+    if ws is None:
+        if len(cache) > 8:
+            cache.clear()
+        ws = cache[key] = LairWorkspace(model, B, K, R, I, device)
+    return ws
+
+
+def lair_cfg(model, ws, *, weighting, scheme, method, cluster_size, weight_alpha):
+    latent, gen = model.engine_dists()
+    try:
+        w = _lib.CS_WEIGHTING[weighting]
+        s = _lib.CS_SCHEME[scheme]
+        m = _lib.CS_METHOD[method]
+    except KeyError:
+        raise NotImplementedError(f"{weighting=}, {scheme=}, {method=}")
+    return _lib.cs_lair_cfg(ws.B, ws.K, ws.R, ws.I, ws.D, ws.Zd, latent, gen, w, s, m,
+                            int(cluster_size or 0), float(1.0 if weight_alpha is None else weight_alpha))
+
+
+def lair_step(model, ws, X, M8, cfg, *, rng=None, draws=None, return_resampled_latents=False,
+              clip_min=None, clip_max=None):
+    """One LAIR iteration in place on ``X`` [B,K,D] (cs_lair_step)."""
+    draws = draws or {}
+    dev = X.device
+    g = lambda k, dt: (draws[k].to(dev, dt).contiguous() if draws.get(k) is not None else None)
+    keep = [g("eps_z", torch.float32), g("eps_x", torch.float32)]
+    systematic = cfg.method == _lib.CS_METHOD["systematic"]
+    if systematic:
+        keep += [g("u_res", torch.float32), g("u_res2", torch.float32)]
+        ud = dict(u_sys=keep[2], u_sys2=keep[3])
+    else:
+        keep += [g("u_res", torch.float64), g("u_res2", torch.float64)]
+        ud = dict(u_res=keep[2], u_res2=keep[3])
+    if return_resampled_latents:
+        ws.want_latents()
+    bufs = _lib.make_bufs(X=X, M=M8, eps_z=keep[0], eps_x=keep[1], q=ws.q, Z=ws.Z, gen=ws.gen, gen_ll=ws.gen_ll,
+                          log_w=ws.log_w, norm_log_w=ws.norm_log_w, idx=ws.idx, ess=ws.stats[0], tess=ws.stats[1],
+                          perplexity=ws.stats[2],
+                          latents_resampled=ws.latents_resampled if return_resampled_latents else None,
+                          idx2=ws.idx2 if return_resampled_latents else None,
+                          clip_min=clip_min, clip_max=clip_max, **ud)
+    rng = rng if rng is not None else _lib.make_rng(0)
+    enc = model.var_latent_network.packed()
+    dec = model.generator_network.packed()
+    _lib.check(_lib.lib().cs_lair_step(enc.handle, dec.handle, C.byref(cfg), C.byref(bufs), C.byref(rng),
+                                       _lib.current_stream()))
+    return ws
+
+
+def decode_params(model, Z):
+    """Generator parameterisation (mean|scale or logits) of latents Z[rows,Zd]."""
+    _, gen = model.engine_dists()
+    Z2 = Z.reshape(-1, Z.shape[-1]).contiguous().float()
+    out = torch.empty(Z2.shape[0], model.generator_network.output_dim, device=Z.device, dtype=torch.float32)
+    dec = model.generator_network.packed()
+    _lib.check(_lib.lib().cs_decode_params(dec.handle, _lib.ptr(Z2), Z2.shape[0], gen, _lib.ptr(out),
+                                           _lib.current_stream()))
+    return out
+
+
+def sample_impute(model, gen, X, M8, K, *, eps=None, rng=None, stream_id=_lib.STREAM_X, clip_min=None,
+                  clip_max=None, zero_missing=False, nonfinite_keep=False):
+    """X[B,K,D] <- X*M + sample(gen)*(1-M) in place (M8 None: X <- sample)."""
+    _, gd = model.engine_dists()
+    D = X.shape[-1]
+    B = X.numel() // (K * D)
+    eps = eps.to(X.device, torch.float32).contiguous() if eps is not None else None
+    rng = rng if rng is not None else _lib.make_rng(0)
+    _lib.check(_lib.lib().cs_sample_impute(_lib.ptr(gen), gd, _lib.ptr(eps), C.byref(rng), stream_id, _lib.ptr(X),
+                                           _lib.ptr(M8), B, K, D, _lib.ptr(clip_min), _lib.ptr(clip_max),
+                                           int(zero_missing) | (2 if nonfinite_keep else 0),
+                                           _lib.current_stream()))
+    return X
+
+
+def rng_normal(rng, stream_id, rows, cols, device):
+    out = torch.empty(rows, cols, device=device, dtype=torch.float32)
+    _lib.check(_lib.lib().cs_rng_normal(C.byref(rng), stream_id, rows, cols, _lib.ptr(out), _lib.current_stream()))
+    return out
+
+
+def rng_uniform(rng, stream_id, rows, cols, device):
+    out = torch.empty(rows, cols, device=device, dtype=torch.float32)
+    _lib.check(_lib.lib().cs_rng_uniform(C.byref(rng), stream_id, rows, cols, _lib.ptr(out), _lib.current_stream()))
+    return out
+
+
+def rng_uniform64(rng, stream_id, rows, cols, device):
+    out = torch.empty(rows, cols, device=device, dtype=torch.float64)
+    _lib.check(_lib.lib().cs_rng_uniform64(C.byref(rng), stream_id, rows, cols, _lib.ptr(out), _lib.current_stream()))
+    return out
+
+
+def vae_sample(model, num_samples, *, rng=None, draws=None, return_latents=False):
+    """x ~ p(x|z), z ~ N(0,I) (irwg/models/vae.py:166-178)."""
+    draws = draws or {}
+    dev = model.device
+    rng = rng if rng is not None else _lib.make_rng(0)
+    Zd = model.latent_dim
+    if draws.get("z") is not None:
+        Z = draws["z"].to(dev, torch.float32).contiguous()
+    else:
+        Z = rng_normal(rng, _lib.STREAM_INIT_Z, num_samples, Zd, dev)
+    gen = decode_params(model, Z)
+    D = gen.shape[-1] // (1 if model.hparams.generator_distribution.name == "bern" else 2)
+    X = torch.empty(num_samples, D, device=dev, dtype=torch.float32)
+    sample_impute(model, gen, X, None, 1, eps=draws.get("eps_x"), rng=rng, stream_id=_lib.STREAM_INIT_X)
+    return (X, Z) if return_latents else X

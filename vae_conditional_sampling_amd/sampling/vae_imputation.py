@@ -1,0 +1,108 @@
+"""Per-iteration functions of the samplers with the reference's signatures, computed by the
+HIP library.
+
+Counterparts of ``irwg/sampling/vae_imputation.py``:
+``importance_resampling_gibbs_iteration`` (:484-726), ``pseudo_gibbs_iteration`` (:19-45),
+``expand_M_dim`` (:14-17).  Two keyword-only extensions exist on every stochastic function:
+``rng`` (a ``_lib.cs_rng`` counter-RNG key) and ``draws`` (dict of injected draws, used by
+the parity tests to feed this engine and the reference the same numbers).
+"""
+import torch
+
+from .. import _lib
+from . import engine
+
+
+def expand_M_dim(M, *, data_channel_dim=None):
+    if data_channel_dim is not None:
+        return M.unsqueeze(data_channel_dim)
+    return M
+
+
+def _check_common(miss_model, accept_reject_xm, data_channel_dim, var_proposal_temperature,
+                  var_proposal_anneal_type_to_prior):
+    if miss_model is not None or accept_reject_xm:
+        raise NotImplementedError("missingness models (MNAR) are not implemented")
+    if data_channel_dim is not None:
+        raise NotImplementedError("data_channel_dim is not implemented")
+    if var_proposal_temperature is not None or var_proposal_anneal_type_to_prior is not None:
+        raise NotImplementedError("proposal tempering / annealing is not implemented")
+
+
+def importance_resampling_gibbs_iteration(model, X, M, num_imp_samples, *, glr_cluster_size=None,
+                                          weighting='dmis', resampling_method='multinomial', resampling_scheme='gr',
+                                          num_prior_replenish_proposals=0,
+                                          weight_transform=None,
+                                          use_historical_proposals=None,
+                                          num_historical_proposals=None,
+                                          history=None,
+                                          miss_model=None,
+                                          accept_reject_xm=False,
+                                          data_channel_dim=None,
+                                          var_proposal_temperature=None,
+                                          var_proposal_anneal_type_to_prior=None,
+                                          return_resampled_latents=False,
+                                          rng=None, draws=None, clip_min=None, clip_max=None, inplace=False):
+    """One LAIR iteration.  Returns the reference's 9-tuple (10 with resampled latents):
+    ``X_new[B,K,D], ess[B], transformed_ess[B], perplexity[B], total_num_props,
+    norm_log_weights[B,I*K'], Z_imp[I,B,K',Zd], log_weights[I,B,K'], acceptance_x
+    (, latents_resampled[B,K',Zd])``.
+
+    ``weight_transform`` may be ``None`` or a float alpha (log-weights are multiplied by it
+    before resampling: the 'poly' transform of the sampler class).  The tensors returned are
+    views of the model's workspace and are overwritten by the next call (clone to keep)."""
+    _check_common(miss_model, accept_reject_xm, data_channel_dim, var_proposal_temperature,
+                  var_proposal_anneal_type_to_prior)
+    if use_historical_proposals:
+        raise NotImplementedError("historical proposals are not implemented")
+    if weighting not in ("dmis", "dmis_within_groups", "smis"):
+        raise NotImplementedError()
+    if resampling_scheme not in ("gr", "glr"):
+        raise NotImplementedError()
+    if resampling_method not in ("multinomial", "systematic"):
+        raise NotImplementedError()
+    if weight_transform is not None and not isinstance(weight_transform, (int, float)):
+        raise NotImplementedError("weight_transform must be None or a scalar multiplier")
+    if weighting == "dmis_within_groups" or resampling_scheme == "glr":
+        assert glr_cluster_size is not None and glr_cluster_size > 1
+    B, K, D = X.shape
+    R = int(num_prior_replenish_proposals)
+    ws = engine.lair_workspace(model, B, K, R, int(num_imp_samples), X.device)
+    cfg = engine.lair_cfg(model, ws, weighting=weighting, scheme=resampling_scheme, method=resampling_method,
+                          cluster_size=glr_cluster_size, weight_alpha=weight_transform)
+    X_new = X if inplace else X.clone()
+    if not X_new.is_contiguous():
+        X_new = X_new.contiguous()
+    engine.lair_step(model, ws, X_new, engine.mask_u8(M), cfg, rng=rng, draws=draws,
+                     return_resampled_latents=return_resampled_latents, clip_min=clip_min, clip_max=clip_max)
+    acceptance_x = torch.tensor(1.)
+    out = (X_new, ws.stats[0], ws.stats[1], ws.stats[2], ws.I * ws.Kp, ws.norm_log_w, ws.Z, ws.log_w, acceptance_x)
+    if return_resampled_latents:
+        out = out + (ws.latents_resampled,)
+    return out
+
+
+def pseudo_gibbs_iteration(model, X, M, clip_values_min=None, clip_values_max=None, *, data_channel_dim=None,
+                           rng=None, draws=None, inplace=False):
+    """z ~ q(z|x), x_m ~ p(x_m|z), impute (vae_imputation.py:19-45).  Returns ``(X_new, Z)``.
+    Non-finite x_m are replaced by the previous value, as in the reference."""
+    if data_channel_dim is not None:
+        raise NotImplementedError("data_channel_dim is not implemented")
+    import ctypes as C
+    draws = draws or {}
+    B, K, D = X.shape
+    ws = engine.lair_workspace(model, B, K, 0, 1, X.device)
+    cfg = engine.lair_cfg(model, ws, weighting="smis", scheme="gr", method="multinomial", cluster_size=0,
+                          weight_alpha=None)
+    X_new = (X if inplace else X.clone()).contiguous()
+    M8 = engine.mask_u8(M)
+    eps_z = draws["eps_z"].to(X.device, torch.float32).contiguous() if draws.get("eps_z") is not None else None
+    bufs = _lib.make_bufs(X=X_new, M=M8, eps_z=eps_z, q=ws.q, Z=ws.Z, gen=ws.gen, gen_ll=ws.gen_ll)
+    rng = rng if rng is not None else _lib.make_rng(0)
+    L = _lib.lib()
+    st = _lib.current_stream()
+    _lib.check(L.cs_lair_encode(model.var_latent_network.packed().handle, C.byref(cfg), C.byref(bufs), st))
+    _lib.check(L.cs_lair_decode(model.generator_network.packed().handle, C.byref(cfg), C.byref(bufs), C.byref(rng), st))
+    engine.sample_impute(model, ws.gen, X_new, M8, K, eps=draws.get("eps_x"), rng=rng, stream_id=_lib.STREAM_X,
+                         clip_min=clip_values_min, clip_max=clip_values_max, nonfinite_keep=True)
+    return X_new, ws.Z[0]

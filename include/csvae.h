@@ -137,6 +137,74 @@ int cs_lair_resample_impute(const cs_lair_cfg* cfg, const cs_lair_bufs* b, const
 int cs_lair_step(const cs_mlp_t* enc, const cs_mlp_t* dec, const cs_lair_cfg* cfg, const cs_lair_bufs* b,
                  const cs_rng* rng, void* stream);
 
+/* ---------------------------------------------------------------------------------------
+ * AC-MWG (test_step_vae_sampling.py:1512-1768).  The imputation history
+ * (ImputationHistoryQueue_with_restrictedavailability, irwg/sampling/utils.py:83-237) is a
+ * caller-allocated ring[hist_len,B,K,D] plus availability counters avail[B,K] (int64) in
+ * device memory; the caller tracks the two host scalars of the reference queue: the slot of
+ * the newest entry (`tail_idx`) and whether the ring has wrapped (`full`).
+ */
+typedef struct {
+  int32_t B, K, D, Zd;
+  int32_t latent_dist, gen_dist;
+  int32_t hist_len;  /* ring capacity (max_history_length) */
+  int32_t hist_tail; /* slot of the newest entry before this call */
+  int32_t hist_full; /* 1 once the ring has wrapped */
+  int32_t reserved;
+  double prior_mixture_probability;
+} cs_acmwg_cfg;
+
+typedef struct {
+  float* X;         /* [B,K,D] imputations, updated in place */
+  const uint8_t* M; /* [B,D] */
+  /* chain state, updated in place */
+  float* Z_old;          /* [B,K,Zd] */
+  float* gen_old;        /* [B,K,2,D] generator mean|scale (Bernoulli: [B,K,D] logits) of Z_old */
+  float* z_old_prior_lp; /* [B,K] log p(Z_old) */
+  float* x_old_lp;       /* [B,K] masked log-likelihood of X under gen_old */
+  /* history */
+  float* ring;    /* [hist_len,B,K,D] */
+  int64_t* avail; /* [B,K] */
+  /* injected draws, any may be NULL (-> counter RNG) */
+  const int64_t* r_hist; /* [B,K] integer in [0, max(avail,1)) (utils.py:225) */
+  const float* eps_z;    /* [B,K,Zd] */
+  const float* z_prior;  /* [B,K,Zd] prior proposal */
+  const float* u_prior;  /* [B,K] */
+  const float* u_accept; /* [B,K] */
+  const float* eps_x;    /* [B,K,D] */
+  /* workspace / outputs */
+  int64_t* slots;     /* [B,K] ring slot of the sampled historical imputation */
+  int64_t* in_off;    /* [B,K] workspace */
+  uint8_t* use_prior; /* [B,K] */
+  float* z_alt;       /* [B,K,Zd] workspace */
+  float* q;           /* [B,K,2,Zd] proposal loc|scale */
+  float* Z_new;       /* [B,K,Zd] */
+  float* gen_new;     /* like gen_old */
+  float* ll_new;      /* [B,K] */
+  uint8_t* accepted;  /* [B,K] */
+  float* log_accept;  /* [B,K] */
+} cs_acmwg_bufs;
+
+/* chain state after the warm-up (test_step_vae_sampling.py:1639-1660): q = enc(X),
+ * Z_old = loc + scale*eps_z, gen_old = dec(Z_old), z_old_prior_lp, x_old_lp. */
+int cs_acmwg_init_state(const cs_mlp_t* enc, const cs_mlp_t* dec, const cs_acmwg_cfg* cfg, const cs_acmwg_bufs* b,
+                        const cs_rng* rng, void* stream);
+/* one MWG step (:1666-1755) including the history index draw (utils.py:190-237), the
+ * availability update (utils.py:94-99) and the enqueue of the new imputations (utils.py:101-113)
+ * into slot (hist_tail+1) % hist_len.  After the call the caller advances its tail/full. */
+int cs_acmwg_step(const cs_mlp_t* enc, const cs_mlp_t* dec, const cs_acmwg_cfg* cfg, const cs_acmwg_bufs* b,
+                  const cs_rng* rng, void* stream);
+/* enqueue_batch (utils.py:101-113): ages the counters when the ring was already full, then
+ * writes X[B,K,D] into slot new_tail. */
+int cs_history_enqueue(float* ring, int64_t* avail, int32_t hist_len, int32_t new_tail, int32_t was_full,
+                       const float* X, int64_t B, int32_t K, int32_t D, void* stream);
+/* update_available_timesteps (utils.py:94-99): avail[mask] = len (mask NULL: all chains). */
+int cs_history_set_available(int64_t* avail, const uint8_t* mask, int64_t chains, int64_t len, void* stream);
+
+/* out[row] = sum_d log N(Z[row,d]; 0, 1): reduce(prior_distr.log_prob(Z), '... d -> ...', 'sum')
+ * (test_step_vae_sampling.py:1655). */
+int cs_stdnormal_logprob_rows(const float* Z, int64_t rows, int32_t Zd, float* out, void* stream);
+
 /* gen[rows,2,D] (mean, scale) or [rows,D] (Bernoulli logits) = generator parameterisation of
  * generator_network(Z[rows,Zd]) (vae.py:171-172,203-256). */
 int cs_decode_params(const cs_mlp_t* dec, const float* Z, int64_t rows, int32_t gen_dist, float* gen, void* stream);
@@ -153,8 +221,18 @@ int cs_sample_impute(const float* gen, int32_t gen_dist, const float* eps, const
                      float* X, const uint8_t* M, int64_t B, int32_t K, int32_t D, const float* clip_min,
                      const float* clip_max, int32_t flags, void* stream);
 
+/* LAIR final resampling (test_step_vae_sampling.py:1998-2009): logw[TI,B,K'] and
+ * Zprops[TI,B,K',Zd] hold the proposals of all TI = T*I stored iterations; per example a
+ * Categorical over the S = TI*K' proposals (flattened '(t i k)') is sampled n times with the
+ * float64 uniforms u[B,n] (NULL -> counter RNG) -> idx[B,n], Zout[B,n,Zd].
+ * cdf_ws: workspace of B*S floats. */
+int cs_final_resample(const float* logw, const float* Zprops, int64_t TI, int64_t B, int32_t Kp, int32_t Zd,
+                      const double* u, const cs_rng* rng, int64_t n, float* cdf_ws, int64_t* idx, float* Zout,
+                      void* stream);
+
 /* Draws the built-in RNG would use, written out for tests: standard normals / uniforms of
- * `stream_id` (CS_STREAM_* in csrc/cs_common.h) for rows [0,rows) x elements [0,cols). */
+ * `stream_id` (CS_STREAM_* in csrc/cs_common.h) for rows example_offset + [0,rows) and
+ * elements [0,cols). */
 int cs_rng_normal(const cs_rng* rng, uint32_t stream_id, int64_t rows, int32_t cols, float* out, void* stream);
 int cs_rng_uniform(const cs_rng* rng, uint32_t stream_id, int64_t rows, int32_t cols, float* out, void* stream);
 int cs_rng_uniform64(const cs_rng* rng, uint32_t stream_id, int64_t rows, int32_t cols, double* out, void* stream);

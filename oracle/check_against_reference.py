@@ -138,6 +138,112 @@ def case_lair(ns, name, *, B, K, R, I, D, Zd, H, nb_enc, nb_dec, seed, scheme="g
     print(f"[ok] {name}")
 
 
+BASE_KW = dict(store_last_n_iterations=-1, store_every_n_iterations=1, imputation_metric_quantiles=[],
+               compute_f1_metric=False, compute_inv_f1_metric=False, compute_bin_accuracy_metric=False,
+               compute_rmse_metric=False, compute_ssim_metric=False, compute_latent_wass_metric=False,
+               imputation_fn="vae_samples")
+
+
+def case_acmwg(ns, name, *, B, K, D, Zd, H, seed, warmup, W, T, p, nkpc=None, cluster=None, R=0):
+    from oracle import cs_oracle_samplers as S
+    enc = O.make_resfc_weights(D, 2 * Zd, 1, H, seed)
+    dec = O.make_resfc_weights(Zd, 2 * D, 1, H, seed + 1)
+    vae = ref_vae(ns, enc, dec)
+    X, M = make_inputs(B, K, D, seed + 2)
+    kw = dict(num_pseudo_warmup_iterations=W, num_mwg_iterations=T, prior_mixture_probability=p,
+              warmup_method=warmup, num_copies=K, **BASE_KW)
+    if warmup == "irwg":
+        kw.update(num_k_per_cluster=nkpc, glr_cluster_size=cluster, num_prior_replenish_proposals=R)
+    tester = ns.test_step.TestVAEAdaptiveCollapsedMetropolisWithinGibbs(**kw)
+    tester.set_model(vae)
+    tape = DrawTape(seed + 3)
+    ref_out = []
+    with torch.no_grad(), tape.recording():
+        for o in tester.sampler(X.clone(), M):
+            ref_out.append({k: (v.clone() if torch.is_tensor(v) else v) for k, v in o.items()})
+    assert len(ref_out) == tester.max_iterations
+    entries = S.compact_tape(tape.entries)
+    src = S.TapeSource(entries)
+    okw = dict(num_pseudo_warmup_iterations=W, num_mwg_iterations=T, prior_mixture_probability=p,
+               warmup_method=warmup, num_k_per_cluster=nkpc, glr_cluster_size=cluster,
+               num_prior_replenish_proposals=R)
+    ora = list(S.acmwg_sampler(enc, dec, X.clone(), M, src, **okw))
+    assert src.pos == len(entries), "oracle did not consume the whole tape"
+    assert len(ora) == len(ref_out)
+    fx = dict(flat_weights("enc", enc)); fx.update(flat_weights("dec", dec))
+    fx.update(S.tape_to_npz_dict(entries))
+    accs, slots = [], []
+    for t, (a, r) in enumerate(zip(ora, ref_out)):
+        close(a["X"], r["X"], f"X[{t}]")
+        assert torch.equal(a["X"], r["X"]), f"X[{t}] not bitwise equal"
+        if "Z" in r:
+            close(a["Z"], r["Z"], f"Z[{t}]")
+        close(torch.as_tensor(a["acceptance"], dtype=torch.float32), torch.as_tensor(r["acceptance"], dtype=torch.float32), "acc")
+        if "accepted" in a:
+            accs.append(a["accepted"].numpy()); slots.append(a["slots"].numpy())
+    fx.update(X0=X.numpy(), M=M.numpy(),
+              cfg=np.array([B, K, D, Zd, H, W, T, nkpc or 0, cluster or 0, R], dtype=np.int64),
+              warmup=np.array(warmup), p=np.float64(p),
+              X_seq=np.stack([r["X"].numpy() for r in ref_out]),
+              Z_last=ref_out[-1]["Z"].numpy(),
+              acceptance=np.array([float(r["acceptance"]) for r in ref_out], dtype=np.float32),
+              accepted=np.stack(accs), slots=np.stack(slots))
+    np.savez_compressed(os.path.join(GOLDEN, f"{name}.npz"), **fx)
+    print(f"[ok] {name}  (iterations {len(ref_out)}, mean acceptance {np.mean(accs):.2f})")
+
+
+def case_lair_sampler(ns, name, *, B, K, R, D, Zd, H, seed, T, n_final=None, freq=1):
+    import tempfile, types
+    from oracle import cs_oracle_samplers as S
+    enc = O.make_resfc_weights(D, 2 * Zd, 1, H, seed)
+    dec = O.make_resfc_weights(Zd, 2 * D, 1, H, seed + 1)
+    vae = ref_vae(ns, enc, dec)
+    X, M = make_inputs(B, K, D, seed + 2)
+    g = torch.Generator().manual_seed(seed + 5)
+    X_true = X[:, 0].clone()
+    tester = ns.test_step.TestVAELatentAdaptiveImportanceResampling(
+        num_iterations=T, num_imp_samples=1, weighting_scheme="dmis", resampling_scheme="gr",
+        resampling_method="multinomial", num_prior_replenish_proposals=R,
+        prior_replenish_iteration_frequency=freq, resample_final_imps=True,
+        resample_final_imps_num_samples=n_final, store_latents=True, num_copies=K, **BASE_KW)
+    tester.set_model(vae)
+    tmp = tempfile.mkdtemp()
+    tester.logger = types.SimpleNamespace(experiment=types.SimpleNamespace(get_logdir=lambda: tmp))
+    batch = (X_true, M[:, 0], torch.arange(B))
+    tape = DrawTape(seed + 3)
+    ref_out = []
+    with torch.no_grad(), tape.recording():
+        tester.on_test_batch_start(batch, 0, 0)
+        for o in tester.sampler(X.clone(), M):
+            ref_out.append({k: (v.clone() if torch.is_tensor(v) else v) for k, v in o.items()})
+        tester.on_test_batch_end(None, batch, 0, 0)
+    final = dict(np.load(os.path.join(tmp, "irwg_imputations_after_final_resampling_0.npz")))
+    entries = tape.entries
+    src = S.TapeSource(entries)
+    ora = list(S.lair_sampler(enc, dec, X.clone(), M, src, num_iterations=T, num_prior_replenish_proposals=R,
+                              prior_replenish_iteration_frequency=freq, store_latents=True, collect_proposals=True))
+    for t, (a, r) in enumerate(zip(ora, ref_out)):
+        assert torch.equal(a["X"], r["X"]), f"X[{t}]"
+        close(a["Z"], r["Z"], "Z"); close(a["is_ess"], torch.as_tensor(r["is_ess"]), "ess")
+    if freq == 1:
+        idx, Zf, imps = S.lair_final_resample(dec, [a["Z_prop"] for a in ora], [a["log_weights"] for a in ora],
+                                              X_true, M, src, num_samples=n_final)
+        assert src.pos == len(entries)
+        close(imps.unsqueeze(0), final["imputations"], "final imputations")
+        close(Zf, final["latents"], "final latents")
+    fx = dict(flat_weights("enc", enc)); fx.update(flat_weights("dec", dec))
+    fx.update(S.tape_to_npz_dict(entries))
+    fx.update(X0=X.numpy(), M=M.numpy(), X_true=X_true.numpy(),
+              cfg=np.array([B, K, R, D, Zd, H, T, n_final or 0, freq], dtype=np.int64),
+              X_seq=np.stack([r["X"].numpy() for r in ref_out]),
+              Z_seq=np.stack([r["Z"].numpy() for r in ref_out]),
+              is_ess=np.array([float(r["is_ess"]) for r in ref_out], dtype=np.float32),
+              final_imputations=final["imputations"], final_latents=final["latents"],
+              final_idx=idx.numpy())
+    np.savez_compressed(os.path.join(GOLDEN, f"{name}.npz"), **fx)
+    print(f"[ok] {name}")
+
+
 def main():
     os.makedirs(GOLDEN, exist_ok=True)
     ns = load_reference()
@@ -152,6 +258,12 @@ def main():
               scheme="glr", weighting="dmis_within_groups", cluster=5)
     case_lair(ns, "lair_miniboone_shape", B=3, K=4, R=1, I=1, D=43, Zd=32, H=256, nb_enc=5, nb_dec=2, seed=606,
               iters=1)
+    case_acmwg(ns, "acmwg_irwg_warmup", B=3, K=5, D=9, Zd=4, H=64, seed=707, warmup="irwg", W=2, T=12, p=0.3,
+               nkpc=4, cluster=5, R=5)
+    case_acmwg(ns, "acmwg_pg_warmup", B=4, K=3, D=7, Zd=3, H=64, seed=808, warmup="pseudo_gibbs", W=3, T=10, p=0.05)
+    case_acmwg(ns, "acmwg_nowarmup_noprior", B=4, K=2, D=6, Zd=3, H=64, seed=909, warmup="none", W=0, T=8, p=0.0)
+    case_lair_sampler(ns, "lair_sampler_final", B=4, K=3, R=1, D=8, Zd=4, H=64, seed=111, T=5)
+    case_lair_sampler(ns, "lair_sampler_final_n5", B=3, K=4, R=1, D=8, Zd=4, H=64, seed=222, T=4, n_final=5)
 
 
 if __name__ == "__main__":

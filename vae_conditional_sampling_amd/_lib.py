@@ -52,6 +52,31 @@ class cs_lair_bufs(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in _LAIR_BUF_FIELDS]
 
 
+class cs_acmwg_cfg(C.Structure):
+    _fields_ = [("B", C.c_int32), ("K", C.c_int32), ("D", C.c_int32), ("Zd", C.c_int32),
+                ("latent_dist", C.c_int32), ("gen_dist", C.c_int32), ("hist_len", C.c_int32),
+                ("hist_tail", C.c_int32), ("hist_full", C.c_int32), ("reserved", C.c_int32),
+                ("prior_mixture_probability", C.c_double)]
+
+
+_ACMWG_BUF_FIELDS = ["X", "M", "Z_old", "gen_old", "z_old_prior_lp", "x_old_lp", "ring", "avail", "r_hist",
+                     "eps_z", "z_prior", "u_prior", "u_accept", "eps_x", "slots", "in_off", "use_prior", "z_alt",
+                     "q", "Z_new", "gen_new", "ll_new", "accepted", "log_accept"]
+
+
+class cs_acmwg_bufs(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in _ACMWG_BUF_FIELDS]
+
+
+def make_acmwg_bufs(**tensors):
+    b = cs_acmwg_bufs()
+    for k, v in tensors.items():
+        if k not in _ACMWG_BUF_FIELDS:
+            raise KeyError(k)
+        setattr(b, k, ptr(v))
+    return b
+
+
 _lib = None
 
 
@@ -74,6 +99,12 @@ def lib():
     L.cs_lair_decode.argtypes = [vp, C.POINTER(cs_lair_cfg), C.POINTER(cs_lair_bufs), C.POINTER(cs_rng), vp]
     L.cs_lair_resample_impute.argtypes = [C.POINTER(cs_lair_cfg), C.POINTER(cs_lair_bufs), C.POINTER(cs_rng), vp]
     L.cs_lair_step.argtypes = [vp, vp, C.POINTER(cs_lair_cfg), C.POINTER(cs_lair_bufs), C.POINTER(cs_rng), vp]
+    L.cs_acmwg_init_state.argtypes = [vp, vp, C.POINTER(cs_acmwg_cfg), C.POINTER(cs_acmwg_bufs), C.POINTER(cs_rng), vp]
+    L.cs_acmwg_step.argtypes = [vp, vp, C.POINTER(cs_acmwg_cfg), C.POINTER(cs_acmwg_bufs), C.POINTER(cs_rng), vp]
+    L.cs_history_enqueue.argtypes = [vp, vp, i32, i32, i32, vp, i64, i32, i32, vp]
+    L.cs_history_set_available.argtypes = [vp, vp, i64, i64, vp]
+    L.cs_final_resample.argtypes = [vp, vp, i64, i64, i32, i32, vp, C.POINTER(cs_rng), i64, vp, vp, vp, vp]
+    L.cs_stdnormal_logprob_rows.argtypes = [vp, i64, i32, vp, vp]
     L.cs_decode_params.argtypes = [vp, vp, i64, i32, vp, vp]
     L.cs_sample_impute.argtypes = [vp, i32, vp, C.POINTER(cs_rng), u32, vp, vp, i64, i32, i32, vp, vp, i32, vp]
     for fn in ("cs_rng_normal", "cs_rng_uniform", "cs_rng_uniform64"):

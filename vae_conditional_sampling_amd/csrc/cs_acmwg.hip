@@ -1,2 +1,300 @@
-// AC-MWG kernels (history ring, fused accept/reject + impute) -- see cs_acmwg entry points.
+// AC-MWG step (TestVAEAdaptiveCollapsedMetropolisWithinGibbs.sampler,
+// irwg/sampling/test_step_vae_sampling.py:1664-1768) and its imputation history
+// (ImputationHistoryQueue_with_restrictedavailability, irwg/sampling/utils.py:83-237).
+//
+// One step = 4 launches on one stream:
+//   prepare   per chain: history index draw -> ring slot -> row offset for the encoder's
+//             gather; prior-mixture Bernoulli; prior proposal                (:1666-1668,1687-1691)
+//   encoder   fused MLP on the gathered historical imputations -> q           (:1671,1683)
+//   decoder   Z_new = loc + scale*eps (or the prior proposal), fused MLP, generator
+//             parameterisation, masked log-likelihood of the current X         (:1684,1718-1725)
+//   accept    proposal log-densities (+ mixture with the prior), acceptance ratio, u < alpha,
+//             availability update, multiply-blend of the chain state, x_m sampling, in-place
+//             imputation, ring write, new log-likelihood                       (:1693-1755)
+// The ring [T,B,K,D] and the availability counters [B,K] live in HBM; the host only tracks the
+// tail slot and the "full" flag, which evolve deterministically.
 #include "cs_mlp.h"
+
+#include <cstring>
+
+struct CsAcmwgArgs {
+  cs_acmwg_cfg cfg;
+  cs_acmwg_bufs b;
+  CsPhilox rng;
+};
+
+__device__ __forceinline__ float wsum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// ---- prepare: one thread per chain ----
+__global__ void __launch_bounds__(256) cs_acmwg_prepare_kernel(const CsAcmwgArgs a) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int B = a.cfg.B, K = a.cfg.K, D = a.cfg.D, Zd = a.cfg.Zd;
+  if (t >= (int64_t)B * K) return;
+  const int64_t grow = a.rng.row_offset * K + t;  // global chain row
+  // uniform index among the available history entries (utils.py:219-237)
+  int64_t bound = a.b.avail[t];
+  if (bound < 1) bound = 1;
+  int64_t r;
+  if (a.b.r_hist) {
+    r = a.b.r_hist[t];
+  } else {
+    uint32_t x[4];
+    cs_philox_block(a.rng, CS_STREAM_HIST, grow, 0, x);
+    r = (int64_t)(((uint64_t)x[0] * (uint64_t)bound) >> 32);
+  }
+  int64_t slot = r;
+  if (a.cfg.hist_full) slot = (r + a.cfg.hist_tail + 1) % a.cfg.hist_len;
+  a.b.slots[t] = slot;
+  a.b.in_off[t] = (slot * B * K + t) * D;
+  // prior-mixture mask and prior proposal (:1687-1691)
+  uint8_t up = 0;
+  if (a.cfg.prior_mixture_probability > 0.0) {
+    const float u = a.b.u_prior ? a.b.u_prior[t] : cs_uniform_elem(a.rng, CS_STREAM_UPRIOR, grow, 0);
+    up = u < (float)a.cfg.prior_mixture_probability;
+    if (up) {
+      for (int d = 0; d < Zd; ++d)
+        a.b.z_alt[t * Zd + d] = a.b.z_prior ? a.b.z_prior[t * Zd + d] : cs_normal_elem(a.rng, CS_STREAM_ZPRIOR, grow, d);
+    }
+  }
+  a.b.use_prior[t] = up;
+}
+
+// ---- accept: one wavefront per chain ----
+__global__ void __launch_bounds__(256) cs_acmwg_accept_kernel(const CsAcmwgArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int64_t t = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int B = a.cfg.B, K = a.cfg.K, D = a.cfg.D, Zd = a.cfg.Zd;
+  if (t >= (int64_t)B * K) return;
+  const int64_t b = t / K;
+  const int64_t grow = a.rng.row_offset * K + t;
+  const double p = a.cfg.prior_mixture_probability;
+  const bool bern = a.cfg.gen_dist == CS_DIST_BERN;
+  const int P = bern ? D : 2 * D;
+
+  // proposal / prior log-densities of Z_new and Z_old (:1693-1715)
+  float zn_q = 0.f, zo_q = 0.f, zn_p = 0.f, zo_p = 0.f;
+  const float* q = a.b.q + t * 2 * Zd;
+  for (int d = lane; d < Zd; d += 64) {
+    const float loc = q[d], sc = q[Zd + d];
+    const float zn = a.b.Z_new[t * Zd + d], zo = a.b.Z_old[t * Zd + d];
+    zn_q += cs_normal_logpdf(zn, loc, sc);
+    zo_q += cs_normal_logpdf(zo, loc, sc);
+    zn_p += cs_stdnormal_logpdf(zn);
+    zo_p += cs_stdnormal_logpdf(zo);
+  }
+  zn_q = wsum(zn_q); zo_q = wsum(zo_q); zn_p = wsum(zn_p); zo_p = wsum(zo_p);
+  const float zn_prior = zn_p;
+  if (p > 0.0) {
+    const float lp = logf((float)p), lq = logf((float)(1.0 - p));
+    {
+      const float x0 = zn_q + lq, x1 = zn_p + lp;
+      float m = fmaxf(x0, x1);
+      if (!(fabsf(m) < INFINITY)) m = 0.f;
+      zn_q = logf(expf(x0 - m) + expf(x1 - m)) + m;
+    }
+    {
+      const float x0 = zo_q + lq, x1 = zo_p + lp;
+      float m = fmaxf(x0, x1);
+      if (!(fabsf(m) < INFINITY)) m = 0.f;
+      zo_q = logf(expf(x0 - m) + expf(x1 - m)) + m;
+    }
+  }
+  const float zold_prior = a.b.z_old_prior_lp[t];
+  const float log_accept = (a.b.ll_new[t] + zn_prior) - (a.b.x_old_lp[t] + zold_prior) + (zo_q - zn_q);
+  const float u = a.b.u_accept ? a.b.u_accept[t] : cs_uniform_elem(a.rng, CS_STREAM_UACC, grow, 0);
+  const bool acc = u < expf(log_accept);
+  const float fa = acc ? 1.0f : 0.0f, fn = acc ? 0.0f : 1.0f;
+
+  if (lane == 0) {
+    a.b.accepted[t] = acc;
+    a.b.log_accept[t] = log_accept;
+    a.b.z_old_prior_lp[t] = zold_prior * fn + zn_prior * fa;
+    // availability (utils.py:94-104): accepted chains see the whole history, then the enqueue
+    // of a full ring ages every chain by one
+    int64_t av = a.b.avail[t];
+    const int64_t len = a.cfg.hist_full ? a.cfg.hist_len : a.cfg.hist_tail + 1;
+    if (acc) av = len;
+    if (a.cfg.hist_full) av = av > 0 ? av - 1 : 0;
+    a.b.avail[t] = av;
+  }
+  // multiply-blend of the chain state (:1739-1743)
+  for (int d = lane; d < Zd; d += 64)
+    a.b.Z_old[t * Zd + d] = a.b.Z_old[t * Zd + d] * fn + a.b.Z_new[t * Zd + d] * fa;
+  // x_m ~ p(x_m | z), imputation, ring write, new masked log-likelihood (:1744-1755)
+  const int new_tail = (a.cfg.hist_tail + 1) % a.cfg.hist_len;
+  float* ring_row = a.b.ring + ((int64_t)new_tail * B * K + t) * D;
+  float ll = 0.f;
+  for (int d = lane; d < D; d += 64) {
+    const float m = (float)a.b.M[b * D + d];
+    const float xo = a.b.X[t * D + d];
+    float xm, lpx;
+    if (bern) {
+      const float l = a.b.gen_old[t * P + d] * fn + a.b.gen_new[t * P + d] * fa;
+      a.b.gen_old[t * P + d] = l;
+      const float ux = a.b.eps_x ? a.b.eps_x[t * D + d] : cs_uniform_elem(a.rng, CS_STREAM_X, grow, d);
+      xm = (ux < cs_sigmoid(l)) ? 1.0f : 0.0f;
+      const float xn = xo * m + xm * (1.0f - m);
+      lpx = cs_bernoulli_logpmf(xn, l);
+      a.b.X[t * D + d] = xn;
+      ring_row[d] = xn;
+    } else {
+      const float mean = a.b.gen_old[t * P + d] * fn + a.b.gen_new[t * P + d] * fa;
+      const float sc = a.b.gen_old[t * P + D + d] * fn + a.b.gen_new[t * P + D + d] * fa;
+      a.b.gen_old[t * P + d] = mean;
+      a.b.gen_old[t * P + D + d] = sc;
+      const float e = a.b.eps_x ? a.b.eps_x[t * D + d] : cs_normal_elem(a.rng, CS_STREAM_X, grow, d);
+      xm = mean + sc * e;
+      const float xn = xo * m + xm * (1.0f - m);
+      lpx = cs_normal_logpdf(xn, mean, sc);
+      a.b.X[t * D + d] = xn;
+      ring_row[d] = xn;
+    }
+    ll += lpx * m;
+  }
+  ll = wsum(ll);
+  if (lane == 0) a.b.x_old_lp[t] = ll;
+}
+
+// ---- small helpers ----
+__global__ void cs_rowsum_stdnormal_kernel(const float* Z, int64_t rows, int Zd, float* out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t t = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (t >= rows) return;
+  float s = 0.f;
+  for (int d = lane; d < Zd; d += 64) s += cs_stdnormal_logpdf(Z[t * Zd + d]);
+  s = wsum(s);
+  if (lane == 0) out[t] = s;
+}
+
+__global__ void cs_history_enqueue_kernel(float* ring_slot, const float* X, int64_t n, int64_t* avail, int64_t chains,
+                                          int was_full) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < n) ring_slot[t] = X[t];
+  if (was_full && t < chains) {
+    const int64_t av = avail[t];
+    avail[t] = av > 0 ? av - 1 : 0;
+  }
+}
+
+__global__ void cs_history_available_kernel(int64_t* avail, const uint8_t* mask, int64_t chains, int64_t len) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < chains && (mask == nullptr || mask[t])) avail[t] = len;
+}
+
+// ----------------------------------------------------------------------------------------
+static int check_acmwg(const cs_acmwg_cfg* c, const cs_acmwg_bufs* b) {
+  CS_REQUIRE(c && b, "null argument");
+  CS_REQUIRE(c->B >= 0 && c->K >= 1 && c->D >= 1 && c->Zd >= 1, "bad sizes");
+  CS_REQUIRE(c->latent_dist == CS_DIST_NORMAL || c->latent_dist == CS_DIST_NORMAL_WITH_EPS,
+             "latent distribution must be normal / normal_with_eps");
+  CS_REQUIRE(c->gen_dist >= CS_DIST_NORMAL && c->gen_dist <= CS_DIST_BERN, "bad generator distribution");
+  CS_REQUIRE(c->prior_mixture_probability >= 0.0 && c->prior_mixture_probability < 1.0,
+             "prior_mixture_probability must be in [0,1)");
+  return CS_OK;
+}
+
+static void fill_mlp_common(CsMlpArgs& a, const cs_acmwg_cfg* c) {
+  a.K = c->K; a.Kp = c->K; a.Zd = c->Zd; a.B = c->B; a.I = 1; a.D = c->D;
+}
+
+// Z = loc + scale*eps from the encoder on X, generator parameters, masked log-likelihood and
+// prior log-density: the chain state after the warm-up (:1639-1660).
+extern "C" int cs_acmwg_init_state(const cs_mlp_t* enc, const cs_mlp_t* dec, const cs_acmwg_cfg* c,
+                                   const cs_acmwg_bufs* b, const cs_rng* rng, void* stream) {
+  if (int rc = check_acmwg(c, b)) return rc;
+  CS_REQUIRE(enc && dec && b->X && b->M && b->q && b->Z_old && b->gen_old && b->z_old_prior_lp && b->x_old_lp,
+             "null argument");
+  if (c->B == 0) return CS_OK;
+  CsMlpArgs e;
+  std::memset(&e, 0, sizeof(e));
+  e.net = enc->dev; e.mode = CS_MLP_ENC; e.rows = (int64_t)c->B * c->K;
+  e.in = b->X; e.in_stride = c->D; e.q = b->q;
+  fill_mlp_common(e, c);
+  e.latent_eps = c->latent_dist == CS_DIST_NORMAL_WITH_EPS;
+  if (int rc = cs_mlp_launch(e, (hipStream_t)stream)) return rc;
+  CsMlpArgs d;
+  std::memset(&d, 0, sizeof(d));
+  d.net = dec->dev; d.mode = CS_MLP_DEC; d.rows = e.rows;
+  fill_mlp_common(d, c);
+  d.q = b->q; d.gen_dist = c->gen_dist; d.eps_z = b->eps_z; d.rng = cs_make_philox(rng);
+  d.Z = b->Z_old; d.gen = b->gen_old; d.gen_ll = b->x_old_lp; d.X = b->X; d.M = b->M;
+  if (int rc = cs_mlp_launch(d, (hipStream_t)stream)) return rc;
+  const int64_t rows = e.rows;
+  hipLaunchKernelGGL(cs_rowsum_stdnormal_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                     b->Z_old, rows, c->Zd, b->z_old_prior_lp);
+  CS_HIP(hipGetLastError());
+  return CS_OK;
+}
+
+extern "C" int cs_acmwg_step(const cs_mlp_t* enc, const cs_mlp_t* dec, const cs_acmwg_cfg* c, const cs_acmwg_bufs* b,
+                             const cs_rng* rng, void* stream) {
+  if (int rc = check_acmwg(c, b)) return rc;
+  CS_REQUIRE(enc && dec && b->X && b->M && b->Z_old && b->gen_old && b->z_old_prior_lp && b->x_old_lp && b->ring &&
+                 b->avail && b->slots && b->in_off && b->use_prior && b->z_alt && b->q && b->Z_new && b->gen_new &&
+                 b->ll_new && b->accepted && b->log_accept,
+             "null argument");
+  CS_REQUIRE(c->hist_len >= 1 && c->hist_tail >= 0 && c->hist_tail < c->hist_len, "bad history state");
+  const bool bern = c->gen_dist == CS_DIST_BERN;
+  CS_REQUIRE(enc->dev.in_dim == c->D && enc->dev.out_dim == 2 * c->Zd && enc->dev.split == 2,
+             "encoder shape does not match the configuration");
+  CS_REQUIRE(dec->dev.in_dim == c->Zd && dec->dev.out_dim == (bern ? 1 : 2) * c->D, "decoder shape mismatch");
+  if (c->B == 0) return CS_OK;
+  hipStream_t st = (hipStream_t)stream;
+  CsAcmwgArgs a;
+  a.cfg = *c; a.b = *b; a.rng = cs_make_philox(rng);
+  const int64_t chains = (int64_t)c->B * c->K;
+  hipLaunchKernelGGL(cs_acmwg_prepare_kernel, dim3((unsigned)((chains + 255) / 256)), dim3(256), 0, st, a);
+  CS_HIP(hipGetLastError());
+  CsMlpArgs e;
+  std::memset(&e, 0, sizeof(e));
+  e.net = enc->dev; e.mode = CS_MLP_ENC; e.rows = chains;
+  e.in = b->ring; e.in_off = b->in_off; e.q = b->q;
+  fill_mlp_common(e, c);
+  e.latent_eps = c->latent_dist == CS_DIST_NORMAL_WITH_EPS;
+  if (int rc = cs_mlp_launch(e, st)) return rc;
+  CsMlpArgs d;
+  std::memset(&d, 0, sizeof(d));
+  d.net = dec->dev; d.mode = CS_MLP_DEC; d.rows = chains;
+  fill_mlp_common(d, c);
+  d.q = b->q; d.gen_dist = c->gen_dist; d.eps_z = b->eps_z; d.rng = a.rng;
+  d.z_override = b->use_prior; d.z_alt = b->z_alt;
+  d.Z = b->Z_new; d.gen = b->gen_new; d.gen_ll = b->ll_new; d.X = b->X; d.M = b->M;
+  if (int rc = cs_mlp_launch(d, st)) return rc;
+  hipLaunchKernelGGL(cs_acmwg_accept_kernel, dim3((unsigned)((chains + 3) / 4)), dim3(256), 0, st, a);
+  CS_HIP(hipGetLastError());
+  return CS_OK;
+}
+
+extern "C" int cs_history_enqueue(float* ring, int64_t* avail, int32_t hist_len, int32_t new_tail, int32_t was_full,
+                                  const float* X, int64_t B, int32_t K, int32_t D, void* stream) {
+  CS_REQUIRE(ring && avail && X && hist_len >= 1 && new_tail >= 0 && new_tail < hist_len, "bad argument");
+  const int64_t chains = B * K, n = chains * D;
+  if (n == 0) return CS_OK;
+  hipLaunchKernelGGL(cs_history_enqueue_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     ring + (int64_t)new_tail * n, X, n, avail, chains, was_full);
+  CS_HIP(hipGetLastError());
+  return CS_OK;
+}
+
+extern "C" int cs_history_set_available(int64_t* avail, const uint8_t* mask, int64_t chains, int64_t len, void* stream) {
+  CS_REQUIRE(avail && chains >= 0, "bad argument");
+  if (chains == 0) return CS_OK;
+  hipLaunchKernelGGL(cs_history_available_kernel, dim3((unsigned)((chains + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, avail, mask, chains, len);
+  CS_HIP(hipGetLastError());
+  return CS_OK;
+}
+
+// sum_d log N(Z[row,d]; 0, 1): prior log-density of the chain state (:1655)
+extern "C" int cs_stdnormal_logprob_rows(const float* Z, int64_t rows, int32_t Zd, float* out, void* stream) {
+  CS_REQUIRE(Z && out && rows >= 0 && Zd >= 1, "bad argument");
+  if (rows == 0) return CS_OK;
+  hipLaunchKernelGGL(cs_rowsum_stdnormal_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                     Z, rows, Zd, out);
+  CS_HIP(hipGetLastError());
+  return CS_OK;
+}

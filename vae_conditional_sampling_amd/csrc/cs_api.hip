@@ -26,8 +26,9 @@ template <int KIND, typename T>
 __global__ void cs_rng_dump_kernel(CsPhilox p, uint32_t stream_id, int64_t rows, int cols, T* out) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= rows * cols) return;
-  const int64_t r = i / cols;
-  const uint32_t e = (uint32_t)(i - r * cols);
+  const int64_t r0 = i / cols;
+  const uint32_t e = (uint32_t)(i - r0 * cols);
+  const int64_t r = p.row_offset + r0;
   if (KIND == 0) out[i] = (T)cs_normal_elem(p, stream_id, r, e);
   else if (KIND == 1) out[i] = (T)cs_uniform_elem(p, stream_id, r, e);
   else out[i] = (T)cs_uniform64_elem(p, stream_id, r, e);
@@ -39,7 +40,6 @@ static int rng_dump(const cs_rng* rng, uint32_t stream_id, int64_t rows, int32_t
   const int64_t n = rows * cols;
   if (n == 0) return CS_OK;
   CsPhilox p = cs_make_philox(rng);
-  p.row_offset = 0;  // rows are absolute here
   hipLaunchKernelGGL((cs_rng_dump_kernel<KIND, T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
                      (hipStream_t)stream, p, stream_id, rows, cols, out);
   CS_HIP(hipGetLastError());

@@ -453,3 +453,98 @@ extern "C" int cs_sample_impute(const float* gen, int32_t gen_dist, const float*
   CS_HIP(hipGetLastError());
   return CS_OK;
 }
+
+// ----------------------------------------------------------------------------------------
+// LAIR final resampling (test_step_vae_sampling.py:1998-2009): per example a Categorical over
+// all S = T*I*K' stored proposals, n draws, gather of the chosen latents.
+// One wavefront per example.  The CDF is the float32 running sum in index order divided by the
+// total with the last entry forced to 1 (torch.multinomial), kept in a caller workspace; each
+// draw is a left bisection with its float64 uniform.
+// ----------------------------------------------------------------------------------------
+struct CsFinalArgs {
+  const float* logw;   // [TI,B,Kp]
+  const float* Zp;     // [TI,B,Kp,Zd]
+  const double* u;     // [B,n] or null
+  CsPhilox rng;
+  float* cdf;          // [B,S] workspace
+  int64_t* idx;        // [B,n]
+  float* Zout;         // [B,n,Zd]
+  int64_t B, TI, n;
+  int Kp, Zd;
+};
+
+__global__ void __launch_bounds__(256) cs_final_resample_kernel(const CsFinalArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int64_t b = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (b >= a.B) return;
+  const int64_t S = a.TI * a.Kp;
+  auto lw_at = [&](int64_t s) { const int64_t ti = s / a.Kp; return a.logw[(ti * a.B + b) * a.Kp + (s - ti * a.Kp)]; };
+  // Categorical(logits): l - logsumexp(l), then softmax
+  float m = -INFINITY;
+  for (int64_t s = lane; s < S; s += 64) m = fmaxf(m, lw_at(s));
+  m = wave_max(m);
+  if (!(fabsf(m) < INFINITY)) m = 0.f;
+  float sum = 0.f;
+  for (int64_t s = lane; s < S; s += 64) sum += expf(lw_at(s) - m);
+  const float lse = logf(wave_sum(sum)) + m;
+  float m2 = -INFINITY;
+  for (int64_t s = lane; s < S; s += 64) m2 = fmaxf(m2, lw_at(s) - lse);
+  m2 = wave_max(m2);
+  float sum2 = 0.f;
+  for (int64_t s = lane; s < S; s += 64) sum2 += expf((lw_at(s) - lse) - m2);
+  sum2 = wave_sum(sum2);
+  // sequential running sum, 64 entries per round
+  float* cdf = a.cdf + b * S;
+  float run = 0.f;
+  for (int64_t s0 = 0; s0 < S; s0 += 64) {
+    const int64_t s = s0 + lane;
+    const float p = s < S ? expf((lw_at(s) - lse) - m2) / sum2 : 0.f;
+    float cum = 0.f;
+    const int cnt = (int)((S - s0) < 64 ? (S - s0) : 64);
+    for (int jj = 0; jj < cnt; ++jj) {
+      run += __shfl(p, jj);
+      if (lane == jj) cum = run;
+    }
+    if (s < S) cdf[s] = cum;
+  }
+  const float total = run;
+  for (int64_t s = lane; s < S; s += 64) cdf[s] = (s == S - 1) ? 1.0f : cdf[s] / total;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  for (int64_t t = lane; t < a.n; t += 64) {
+    const double u = a.u ? a.u[b * a.n + t]
+                         : cs_uniform64_elem(a.rng, CS_STREAM_UFINAL, a.rng.row_offset + b, (uint32_t)t);
+    int64_t lo = 0, hi = S;
+    while (hi - lo > 0) {
+      const int64_t mid = lo + (hi - lo) / 2;
+      if ((double)cdf[mid] < u) lo = mid + 1; else hi = mid;
+    }
+    if (lo > S - 1) lo = S - 1;
+    a.idx[b * a.n + t] = lo;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  for (int64_t e = lane; e < a.n * a.Zd; e += 64) {
+    const int64_t t = e / a.Zd;
+    const int d = (int)(e - t * a.Zd);
+    const int64_t s = a.idx[b * a.n + t];
+    const int64_t ti = s / a.Kp;
+    a.Zout[(b * a.n + t) * a.Zd + d] = a.Zp[((ti * a.B + b) * a.Kp + (s - ti * a.Kp)) * a.Zd + d];
+  }
+}
+
+extern "C" int cs_final_resample(const float* logw, const float* Zprops, int64_t TI, int64_t B, int32_t Kp, int32_t Zd,
+                                 const double* u, const cs_rng* rng, int64_t n, float* cdf_ws, int64_t* idx,
+                                 float* Zout, void* stream) {
+  CS_REQUIRE(logw && Zprops && cdf_ws && idx && Zout, "null argument");
+  CS_REQUIRE(TI >= 1 && B >= 0 && Kp >= 1 && Zd >= 1 && n >= 1, "bad sizes");
+  if (B == 0) return CS_OK;
+  CsFinalArgs a;
+  a.logw = logw; a.Zp = Zprops; a.u = u; a.rng = cs_make_philox(rng); a.cdf = cdf_ws; a.idx = idx; a.Zout = Zout;
+  a.B = B; a.TI = TI; a.n = n; a.Kp = Kp; a.Zd = Zd;
+  hipLaunchKernelGGL(cs_final_resample_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);
+  CS_HIP(hipGetLastError());
+  return CS_OK;
+}

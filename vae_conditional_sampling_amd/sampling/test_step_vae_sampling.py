@@ -1,0 +1,695 @@
+"""Sampler classes with the reference's names, constructor arguments and generator protocol,
+running on the HIP library.
+
+Counterparts in irwg/sampling/test_step_vae_sampling.py:
+  TestVAESamplerBase                                 :102-1000 (the parts LAIR / AC-MWG use)
+  TestVAELatentAdaptiveImportanceResampling (LAIR)   :1770-2061
+  TestVAEAdaptiveCollapsedMetropolisWithinGibbs      :1457-1768
+
+Extensions that do not exist in the reference (all optional):
+  * ``rng_seed`` / ``example_offset`` attributes key the counter RNG (global example index, so a
+    sharded run draws the same numbers as an unsharded one);
+  * ``draw_source``: an object with ``normal/uniform/uniform64/randint`` methods that supplies
+    every random draw in the reference's call order (used by the parity tests to replay a tape
+    recorded from the reference);
+  * ``out_dir``: where ``.npz`` artefacts go (the reference uses the Lightning logger's dir).
+"""
+import math
+import os
+from collections import defaultdict
+from typing import Any, List
+
+import numpy as np
+import torch
+
+from .. import _lib
+from ..utils.hparams import HyperparametersMixin
+from . import engine
+from .utils import ImputationHistoryQueue_with_restrictedavailability
+from .vae_imputation import importance_resampling_gibbs_iteration, pseudo_gibbs_iteration
+
+_DIAGNOSTIC_FLAGS = ("compute_f1_metric", "compute_inv_f1_metric", "compute_bin_accuracy_metric",
+                     "compute_rmse_metric", "compute_ssim_metric", "compute_latent_wass_metric",
+                     "compute_mae_metric", "estimate_sampler_ess", "estimate_mmd_with_model",
+                     "estimate_mmd_for_full_chain", "estimate_iwelbo", "estimate_kl_div_for_full_chain",
+                     "estimate_kl_div", "estimate_fid_chain", "estimate_kid_chain", "estimate_mog_kldivs",
+                     "estimate_sampler_variance", "save_img_snapshot_in_tb")
+
+
+def _check_if_bool(X):
+    return bool(((X == 0).sum() + (X == 1).sum()) == X.numel())
+
+
+class TestVAESamplerBase(HyperparametersMixin):
+    """Samplers for VAE, base class (harness: chain set-up, initial imputation, loop over the
+    sampler generator, storage of the imputation sequence)."""
+    __test__ = False  # not a pytest class
+
+    def __init__(self,
+                 store_last_n_iterations: int,
+                 store_every_n_iterations: int,
+
+                 imputation_metric_quantiles: List[float],
+                 compute_f1_metric: bool,
+                 compute_inv_f1_metric: bool,
+                 compute_bin_accuracy_metric: bool,
+                 compute_rmse_metric: bool,
+                 compute_ssim_metric: bool,
+                 compute_latent_wass_metric: bool,
+
+                 num_copies: int,
+                 imputation_fn: str,
+
+                 store_latents: bool = False,
+                 dont_store_imputations: bool = False,
+
+                 sgd_map_init_num_particles: int = None,
+                 sgd_map_init_sgd_steps: int = None,
+                 sgd_map_init_sgd_lr: float = None,
+                 sgd_map_init_use_lr_sched: bool = False,
+
+                 num_sequential_runs: int = 1,
+
+                 save_img_snapshot_in_tb: bool = False,
+                 snapshot_image_dims: List[int] = [28, 28],
+
+                 estimate_sampler_ess: bool = False,
+                 sampler_ess_estimator_warmup: int = -1,
+                 ess_evaluation_batchsize: int = -1,
+                 normalise_trajectory_ess_by_is_ess: bool = False,
+                 store_is_norm_ess: bool = False,
+
+                 estimate_mmd_with_model: bool = False,
+                 mmd_estimator_kernel: str = 'rbf',
+                 mmd_estimator_size: int = None,
+                 mmd_estimator_frequency: int = None,
+                 mmd_avg_of_chains: bool = False,
+                 estimate_mmd_for_full_chain: bool = False,
+                 estimate_mmd_target_num_repeats: int = 1,
+                 mmd_full_chain_linear_estimator_repeats: int = 1,
+
+                 estimate_iwelbo: bool = False,
+                 iwelbo_estimator_frequency: int = None,
+                 iwelbo_num_importance_samples: int = None,
+                 iwelbo_batchsize: int = -1,
+
+                 estimate_kl_div_for_full_chain: bool = False,
+                 kl_div_kde_kernel: str = 'rbf',
+                 kl_div_iwelbo_num_importance_samples: int = None,
+                 estimate_kl_div: bool = False,
+                 kl_div_estimator_frequency: int = None,
+
+                 estimate_fid_chain: bool = False,
+                 fid_estimator_size: int = None,
+
+                 estimate_kid_chain: bool = False,
+                 kid_estimator_kernel: str = None,
+                 kid_full_chain_linear_estimator_repeats: int = None,
+
+                 estimate_mog_kldivs: bool = False,
+                 num_mog_em_iterations: int = None,
+                 num_mog_kl_samples: int = None,
+                 mog_kldivs_skip_first_num_imps: int = None,
+                 mog_kldivs_use_every_nth: int = 1,
+                 mog_em_use_solver: bool = False,
+                 estimate_mog_jsd: bool = False,
+
+                 estimate_sampler_variance: bool = False,
+
+                 compute_mae_metric: bool = False,
+
+                 data_channel_dim: int = None,
+
+                 ssim_image_dims: List[int] = [1, 28, 28],
+                 ):
+        super().__init__()
+        self.save_hyperparameters()
+        assert not estimate_sampler_ess or sampler_ess_estimator_warmup > 0
+        # engine-side state (not in the reference)
+        self.rng_seed = 0
+        self.example_offset = 0
+        self.draw_source = None
+        self.out_dir = None
+        self.skip_unimplemented_diagnostics = False
+        self._iteration = 0
+
+    # ---- wiring -------------------------------------------------------------------------
+    def set_model(self, model):
+        self.model = model
+
+    def set_datamodule(self, datamodule):
+        self.datamodule = datamodule
+
+    @property
+    def device(self):
+        return self.model.device
+
+    def on_test_start(self):
+        enabled = [f for f in _DIAGNOSTIC_FLAGS if self.hparams.get(f)]
+        if enabled and not self.skip_unimplemented_diagnostics:
+            raise NotImplementedError(f"per-iteration diagnostics are not implemented: {enabled} "
+                                      "(set skip_unimplemented_diagnostics=True to run without them)")
+        if self.hparams.data_channel_dim is not None:
+            raise NotImplementedError("data_channel_dim is not implemented")
+        if self.hparams.num_sequential_runs != 1:
+            raise NotImplementedError("num_sequential_runs != 1 is not implemented")
+
+    def on_test_epoch_start(self):
+        self.metrics = defaultdict(list)
+
+    def on_test_batch_start(self, batch: Any, batch_idx: int, dataloader_idx: int = 0) -> None:
+        pass
+
+    def on_test_batch_end(self, outputs, batch: Any, batch_idx: int, dataloader_idx: int = 0) -> None:
+        pass
+
+    def test_epoch_end(self, outputs):
+        return outputs
+
+    # ---- random draws -------------------------------------------------------------------
+    def _rng(self, stream_iteration=None):
+        it = self._iteration if stream_iteration is None else stream_iteration
+        return _lib.make_rng(self.rng_seed, it, self.example_offset)
+
+    def _next_iteration(self):
+        self._iteration += 1
+
+    # ---- to be implemented by subclasses ------------------------------------------------
+    def sampler(self, X, M):
+        raise NotImplementedError()
+
+    @property
+    def max_iterations(self):
+        raise NotImplementedError()
+
+    # ---- initial imputation (test_step_vae_sampling.py:276-297) -------------------------
+    def basic_imputation(self, X, M):
+        if self.hparams.imputation_fn != 'vae_samples':
+            raise NotImplementedError(f"imputation_fn={self.hparams.imputation_fn!r} (only 'vae_samples')")
+        B, K, D = X.shape
+        src = self.draw_source
+        draws = None
+        if src is not None:
+            bern = self.model.hparams.generator_distribution.name == "bern"
+            draws = {"z": src.normal(B * K, self.model.latent_dim),
+                     "eps_x": src.uniform(B * K, D) if bern else src.normal(B * K, D)}
+        # rng rows are (example_offset + b)*K + k of a dedicated stream: independent of batching
+        rng = _lib.make_rng(self.rng_seed, 0, self.example_offset * K)
+        Z = (draws["z"].to(X.device, torch.float32).contiguous() if draws is not None
+             else engine.rng_normal(rng, _lib.STREAM_INIT_Z, B * K, self.model.latent_dim, X.device))
+        gen = engine.decode_params(self.model, Z)
+        Xn = X.clone().contiguous()
+        rng_x = _lib.make_rng(self.rng_seed, 0, self.example_offset)
+        engine.sample_impute(self.model, gen, Xn, engine.mask_u8(M), K, eps=draws["eps_x"] if draws else None,
+                             rng=rng_x, stream_id=_lib.STREAM_INIT_X, zero_missing=True)
+        return Xn
+
+    # ---- harness (test_step_vae_sampling.py:344-416, 488-496, 766-791) -------------------
+    def test_step(self, batch, batch_idx: int):
+        X_true, M = batch[:2]
+        I = batch[-1]
+        dev = self.device
+        X_true = X_true.to(dev, torch.float32)
+        M = M.to(dev).bool()
+        bool_data = _check_if_bool(X_true[M])
+        K = self.hparams.num_copies
+        X = X_true.unsqueeze(1).repeat(1, K, *([1] * (X_true.dim() - 1))).contiguous()
+        M = M.unsqueeze(1)
+        X_true1 = X_true.unsqueeze(1)
+        hp = self.hparams
+        imputations, latents = [], ([] if hp.store_latents else None)
+        self._iteration = 0
+        X = self.basic_imputation(X, M)
+        imputations.append(X.clone())
+        t = -1
+        outputs = None
+        for t, outputs in enumerate(self.sampler(X, M)):
+            X = outputs['X']
+            if ((hp.store_last_n_iterations == -1 or (self.max_iterations - hp.store_last_n_iterations) <= t)
+                    and t % hp.store_every_n_iterations == 0):
+                imputations.append(X.clone())
+                if hp.store_latents:
+                    latents.append(outputs['Z'].clone())
+            for key, val in outputs.items():
+                if key in ('X', 'Z', 'is_ess_not_reduced', 'total_num_props') or key.startswith('_'):
+                    continue
+                self.metrics[key].append(val)
+        if t >= 0 and ((hp.store_last_n_iterations == -1 or (self.max_iterations - hp.store_last_n_iterations) <= t)
+                       and not (t % hp.store_every_n_iterations == 0)):
+            imputations.append(X.clone())
+            if hp.store_latents:
+                latents.append(outputs['Z'].clone())
+        # one device->host transfer for the whole sequence
+        imps = torch.stack(imputations).cpu().numpy()
+        if bool_data:
+            imps = imps.astype(bool)
+        lat = torch.stack(latents).cpu().numpy() if latents else []
+        self.last_imputations = imps
+        if not hp.dont_store_imputations and self.out_dir is not None:
+            os.makedirs(self.out_dir, exist_ok=True)
+            np.savez_compressed(os.path.join(self.out_dir, f'imputations_{batch_idx}.npz'),
+                                imputations=imps, latents=lat, true_X=X_true1.cpu().numpy(),
+                                masks=M.cpu().numpy(), data_idx=np.asarray(I.cpu() if torch.is_tensor(I) else I))
+        return {k: [float(v) if not torch.is_tensor(v) else float(v) for v in vals] for k, vals in self.metrics.items()}
+
+
+class TestVAELatentAdaptiveImportanceResampling(TestVAESamplerBase):
+    """IRWG sampling, called LAIR (latent-adaptive importance resampling) in the paper."""
+
+    def __init__(self,
+                 num_iterations: int,
+                 num_imp_samples: int,
+                 weighting_scheme: str,
+                 resampling_scheme: str,
+                 resampling_method: str,
+                 *args,
+                 glr_cluster_size: int = None,
+                 num_pseudo_warmup_iterations: int = 0,
+                 num_prior_replenish_proposals: int = 0,
+                 prior_replenish_iteration_frequency: int = 1,
+
+                 var_proposal_temperature: float = None,
+                 var_proposal_anneal_type_to_prior: str = None,
+
+                 weight_transform: str = None,
+                 clip_imputations: bool = False,
+
+                 num_historical_proposals: int = None,
+                 no_historic_proposals_iterations: int = None,
+                 imputation_history_length: int = None,
+
+                 use_miss_model: bool = False,
+                 accept_reject_xm: bool = False,
+
+                 store_norm_log_weights: bool = False,
+
+                 resample_final_imps: bool = False,
+                 resample_final_imps_num_samples: int = None,
+                 **kwargs
+                 ):
+        super().__init__(*args, **kwargs)
+        self.save_hyperparameters()
+
+    @property
+    def max_iterations(self):
+        return self.hparams.num_iterations
+
+    def on_test_start(self):
+        super().on_test_start()
+        hp = self.hparams
+        if hp.num_historical_proposals is not None:
+            raise NotImplementedError("historical proposals are not implemented")
+        if hp.use_miss_model or hp.accept_reject_xm:
+            raise NotImplementedError("missingness models (MNAR) are not implemented")
+        if hp.var_proposal_temperature is not None or hp.var_proposal_anneal_type_to_prior is not None:
+            raise NotImplementedError("proposal tempering / annealing is not implemented")
+        if hp.weight_transform not in (None, 'poly'):
+            raise NotImplementedError()
+
+    def on_test_epoch_start(self):
+        super().on_test_epoch_start()
+        if self.hparams.store_norm_log_weights:
+            self.norm_log_weights = []
+
+    def on_test_batch_start(self, batch: Any, batch_idx: int, dataloader_idx: int = 0) -> None:
+        super().on_test_batch_start(batch, batch_idx, dataloader_idx)
+        self._proposals = None  # device store [T,I,B,K',Zd] / [T,I,B,K'] for the final resampling
+
+    def polynomial_transform(self, log_weights, iter, max_iter):
+        alpha = min((iter + 10) / max_iter, 1)
+        return log_weights * alpha
+
+    def _draws(self, B, K, R, D, second):
+        src = self.draw_source
+        if src is None:
+            return None
+        hp = self.hparams
+        I, Kp, Zd = hp.num_imp_samples, K + R, self.model.latent_dim
+        bern = self.model.hparams.generator_distribution.name == "bern"
+        d = {"eps_z": src.normal(I, B, Kp, Zd)}
+        G = Kp // hp.glr_cluster_size if hp.resampling_scheme == 'glr' else 1
+
+        def res():
+            if hp.resampling_method == 'multinomial':
+                return src.uniform64(B * G, Kp // G)
+            return src.uniform(B, 1) if hp.resampling_scheme == 'gr' else src.uniform(B, G, 1)
+        d["u_res"] = res()
+        if second:
+            d["u_res2"] = res()
+        d["eps_x"] = src.uniform(B, K, D) if bern else src.normal(B, K, D)
+        return d
+
+    def sampler(self, X, M):
+        hp = self.hparams
+        B, K, D = X.shape
+        clip_min = clip_max = None
+        if hp.clip_imputations:
+            X_temp = X[:, 0].clone()
+            X_temp *= M.squeeze(1)
+            clip_max = (torch.max(X_temp, dim=0)[0] * 2).contiguous()
+            clip_min = (torch.min(X_temp, dim=0)[0] * 2).contiguous()
+            del X_temp
+        X = X.clone().contiguous()
+
+        if hp.num_pseudo_warmup_iterations > 0:
+            for t in range(hp.num_pseudo_warmup_iterations):
+                draws = None
+                if self.draw_source is not None:
+                    draws = {"eps_z": self.draw_source.normal(B, K, self.model.latent_dim),
+                             "eps_x": self.draw_source.normal(B, K, D)}
+                X, Z_imp = pseudo_gibbs_iteration(self.model, X, M, rng=self._rng(), draws=draws, inplace=True)
+                self._next_iteration()
+                yield {'X': X, 'Z': Z_imp.clone(), 'is_ess': 0., 'is_ess_not_reduced': torch.zeros(B),
+                       'total_num_props': 1.}
+
+        all_norm_log_weights = []
+        T = hp.num_iterations
+        for t in range(T):
+            weight_transform = None
+            if hp.weight_transform == 'poly':
+                weight_transform = min((t + 10) / self.max_iterations, 1)
+            R = hp.num_prior_replenish_proposals if t % hp.prior_replenish_iteration_frequency == 0 else 0
+            ret = importance_resampling_gibbs_iteration(
+                self.model, X, M, hp.num_imp_samples, glr_cluster_size=hp.glr_cluster_size,
+                weighting=hp.weighting_scheme, resampling_method=hp.resampling_method,
+                resampling_scheme=hp.resampling_scheme, num_prior_replenish_proposals=R,
+                weight_transform=weight_transform, return_resampled_latents=bool(hp.store_latents),
+                rng=self._rng(), draws=self._draws(B, K, R, D, bool(hp.store_latents)),
+                clip_min=clip_min, clip_max=clip_max, inplace=True)
+            self._next_iteration()
+            X, ess, transformed_ess, perplexity, total_num_props, norm_log_weights, Z_prop, log_weights = ret[:8]
+            latents = ret[9].clone() if hp.store_latents else None  # (the reference fails without store_latents)
+
+            if hp.resample_final_imps:
+                if self._proposals is None:
+                    if hp.prior_replenish_iteration_frequency != 1 and hp.num_prior_replenish_proposals > 0:
+                        raise NotImplementedError("final resampling with a varying number of proposals")
+                    self._proposals = (torch.empty((T,) + tuple(Z_prop.shape), device=X.device),
+                                       torch.empty((T,) + tuple(log_weights.shape), device=X.device))
+                self._proposals[0][t].copy_(Z_prop)
+                self._proposals[1][t].copy_(log_weights)
+            if hp.store_norm_log_weights:
+                all_norm_log_weights.append(norm_log_weights.clone())
+
+            yield {'X': X,
+                   'Z': latents,
+                   'is_ess': ess.mean(),
+                   'is_ess_not_reduced': ess,
+                   'transformed_ess': transformed_ess.mean(),
+                   'perplexity': perplexity.mean(),
+                   'total_num_props': total_num_props,
+                   'acceptance_x': 1.0,
+                   }
+
+        if hp.store_norm_log_weights:
+            self.norm_log_weights.append(torch.stack(all_norm_log_weights, dim=1).cpu().numpy())
+
+    def final_resampling(self, X_true, M):
+        """Resample the latents across all iterations and decode (:1991-2032).  Returns
+        ``(imputations[1,B,n,D], latents[B,n,Zd], idx[B,n])`` as device tensors."""
+        hp = self.hparams
+        Zp, lw = self._proposals
+        T, I, B, Kp, Zd = Zp.shape
+        n = T * Kp if hp.resample_final_imps_num_samples is None else hp.resample_final_imps_num_samples
+        dev = Zp.device
+        src = self.draw_source
+        u = src.uniform64(B, n).to(dev).contiguous() if src is not None else None
+        cdf = torch.empty(B, T * I * Kp, device=dev)
+        idx = torch.empty(B, n, device=dev, dtype=torch.int64)
+        Zout = torch.empty(B, n, Zd, device=dev)
+        import ctypes as C
+        rng = _lib.make_rng(self.rng_seed, 0, self.example_offset)
+        _lib.check(_lib.lib().cs_final_resample(_lib.ptr(lw), _lib.ptr(Zp), T * I, B, Kp, Zd, _lib.ptr(u),
+                                                C.byref(rng), n, _lib.ptr(cdf), _lib.ptr(idx), _lib.ptr(Zout),
+                                                _lib.current_stream()))
+        gen = engine.decode_params(self.model, Zout.reshape(B * n, Zd))
+        D = X_true.shape[-1]
+        Xz = X_true.to(dev, torch.float32).unsqueeze(1).repeat(1, n, 1).contiguous()
+        eps = None
+        if src is not None:
+            bern = self.model.hparams.generator_distribution.name == "bern"
+            chunks = [(src.uniform if bern else src.normal)(B, min(Kp, n - c0), D) for c0 in range(0, n, Kp)]
+            eps = torch.cat(chunks, dim=1)
+        engine.sample_impute(self.model, gen, Xz, engine.mask_u8(M), n, eps=eps, rng=rng,
+                             stream_id=_lib.STREAM_UFINAL, zero_missing=True)
+        return Xz.unsqueeze(0), Zout, idx
+
+    def on_test_batch_end(self, outputs, batch: Any, batch_idx: int, dataloader_idx: int = 0) -> None:
+        super().on_test_batch_end(outputs, batch, batch_idx, dataloader_idx)
+        if not self.hparams.resample_final_imps:
+            return
+        X_true, M = batch[:2]
+        I = batch[-1]
+        dev = self.device
+        M1 = M.to(dev).bool().unsqueeze(1)
+        imps, Z, _ = self.final_resampling(X_true, M1)
+        bool_data = _check_if_bool(X_true.to(dev)[M.to(dev).bool()])
+        imps = imps.cpu().numpy()
+        if bool_data:
+            imps = imps.astype(bool)
+        self.last_final_imputations = imps
+        if self.out_dir is not None:
+            os.makedirs(self.out_dir, exist_ok=True)
+            np.savez_compressed(os.path.join(self.out_dir, f'irwg_imputations_after_final_resampling_{batch_idx}.npz'),
+                                imputations=imps, latents=Z.cpu().numpy() if self.hparams.store_latents else [],
+                                true_X=X_true.unsqueeze(1).cpu().numpy(), masks=M1.cpu().numpy(),
+                                data_idx=np.asarray(I.cpu() if torch.is_tensor(I) else I))
+
+    def test_epoch_end(self, outputs):
+        out = super().test_epoch_end(outputs)
+        if self.hparams.store_norm_log_weights and self.out_dir is not None:
+            np.savez_compressed(os.path.join(self.out_dir, 'is_norm_log_weights.npz'),
+                                is_norm_log_weights=np.concatenate(self.norm_log_weights))
+        return out
+
+
+class TestVAEAdaptiveCollapsedMetropolisWithinGibbs(TestVAESamplerBase):
+    """Metropolis-within-Gibbs sampling with marginalised missing values, called AC-MWG
+    (adaptive collapsed-Metropolis-within-Gibbs) in the paper."""
+
+    def __init__(self,
+                 num_pseudo_warmup_iterations: int,
+                 num_mwg_iterations: int,
+                 prior_mixture_probability: float,
+
+                 *args,
+                 enqueue_allwarmup_samples_to_history: bool = False,
+                 warmup_method: str = 'pseudo_gibbs',
+                 clip_imputations_during_pg_warmup: bool = False,
+                 clipping_mode: str = 'batch_data',
+                 var_proposal_temperature: float = None,
+                 var_proposal_anneal_type_to_prior: str = None,
+                 num_prior_replenish_proposals: int = 0,
+
+                 # IRWG warmup
+                 num_k_per_cluster: int = None,
+                 num_imp_samples: int = 1,
+                 weighting_scheme: str = 'dmis_within_groups',
+                 resampling_scheme: str = 'glr',
+                 resampling_method: str = 'multinomial',
+                 glr_cluster_size: int = None,
+
+                 ablation_use_mwg_target: bool = False,
+
+                 **kwargs,
+                 ):
+        super().__init__(*args, **kwargs)
+        self.save_hyperparameters()
+        if self.hparams.warmup_method == 'irwg':
+            assert (self.hparams.num_k_per_cluster
+                    + self.hparams.num_prior_replenish_proposals / self.hparams.glr_cluster_size) == self.hparams.glr_cluster_size
+
+    @property
+    def max_iterations(self):
+        if self.hparams.warmup_method != 'irwg':
+            return self.hparams.num_pseudo_warmup_iterations + self.hparams.num_mwg_iterations
+        return (self.hparams.num_pseudo_warmup_iterations * self.hparams.num_k_per_cluster) + self.hparams.num_mwg_iterations
+
+    def on_test_start(self):
+        super().on_test_start()
+        hp = self.hparams
+        if hp.ablation_use_mwg_target:
+            raise NotImplementedError("ablation_use_mwg_target is not implemented")
+        if hp.var_proposal_temperature is not None or hp.var_proposal_anneal_type_to_prior is not None:
+            raise NotImplementedError("proposal tempering / annealing is not implemented")
+        if hp.warmup_method not in ('none', 'pseudo_gibbs', 'irwg'):
+            raise NotImplementedError(f'{hp.warmup_method=}')
+
+    def _lair_warmup_draws(self, B, Kw, R, D):
+        src = self.draw_source
+        if src is None:
+            return None
+        hp = self.hparams
+        I, Kp, Zd = hp.num_imp_samples, Kw + R, self.model.latent_dim
+        d = {"eps_z": src.normal(I, B, Kp, Zd)}
+        G = Kp // hp.glr_cluster_size if hp.resampling_scheme == 'glr' else 1
+        if hp.resampling_method == 'multinomial':
+            d["u_res"] = src.uniform64(B * G, Kp // G)
+        else:
+            d["u_res"] = src.uniform(B, 1) if hp.resampling_scheme == 'gr' else src.uniform(B, G, 1)
+        d["eps_x"] = src.normal(B, Kw, D)
+        return d
+
+    def sampler(self, X, M):
+        import ctypes as C
+        hp = self.hparams
+        model = self.model
+        src = self.draw_source
+        B, K, D = X.shape
+        Zd = model.latent_dim
+        dev = X.device
+        latent, gen_dist = model.engine_dists()
+        bern = gen_dist == _lib.CS_DIST["bern"]
+        P = model.generator_network.output_dim
+        M8 = engine.mask_u8(M)
+        X = X.clone().contiguous()
+
+        clip_values_max, clip_values_min = None, None
+        if hp.clip_imputations_during_pg_warmup:
+            if hp.clipping_mode == 'batch_data':
+                X_temp = X[:, 0].clone()
+                X_temp *= M.squeeze(1)
+                clip_values_max = (torch.max(X_temp, dim=0)[0] * 2).contiguous()
+                clip_values_min = (torch.min(X_temp, dim=0)[0] * 2).contiguous()
+            elif hp.clipping_mode == 'dataset':
+                clip_values_max = torch.tensor(self.datamodule.test_data_core.data_max * 2, device=dev,
+                                               dtype=torch.float32).contiguous()
+                clip_values_min = torch.tensor(self.datamodule.test_data_core.data_min * 2, device=dev,
+                                               dtype=torch.float32).contiguous()
+            else:
+                raise NotImplementedError(f'Invalid {hp.clipping_mode=}')
+
+        bool_data = _check_if_bool(X)
+        history = ImputationHistoryQueue_with_restrictedavailability(
+            max_history_length=self.max_iterations, batch_shape=X.shape,
+            dtype=X.dtype if not bool_data else torch.bool, device=dev)
+        self.history = history
+
+        if hp.warmup_method == 'none':
+            history.enqueue_batch(X)
+        elif hp.warmup_method == 'pseudo_gibbs':
+            W = hp.num_pseudo_warmup_iterations
+            for t in range(W):
+                draws = None
+                if src is not None:
+                    draws = {"eps_z": src.normal(B, K, Zd), "eps_x": src.uniform(B, K, D) if bern else src.normal(B, K, D)}
+                if hp.clip_imputations_during_pg_warmup:
+                    X, Z_new = pseudo_gibbs_iteration(model, X, M, clip_values_min, clip_values_max, rng=self._rng(),
+                                                      draws=draws, inplace=True)
+                else:
+                    X, Z_new = self._pg_step_noclip(X, M, M8, draws)
+                self._next_iteration()
+                if hp.enqueue_allwarmup_samples_to_history or t == W - 1:
+                    history.enqueue_batch(X)
+                yield {'X': X, 'Z': Z_new.clone(), 'acceptance': 1.}
+        elif hp.warmup_method == 'irwg':
+            c, R = hp.glr_cluster_size, hp.num_prior_replenish_proposals
+            Kw = K * hp.num_k_per_cluster
+            X_w = X[:, :1].expand(B, Kw, D).contiguous()
+            X_w = self.basic_imputation(X_w, M)
+            W = hp.num_pseudo_warmup_iterations
+            for t in range(W):
+                ret = importance_resampling_gibbs_iteration(
+                    model, X_w, M, hp.num_imp_samples, glr_cluster_size=c, weighting=hp.weighting_scheme,
+                    resampling_method=hp.resampling_method, resampling_scheme=hp.resampling_scheme,
+                    num_prior_replenish_proposals=R, rng=self._rng(), draws=self._lair_warmup_draws(B, Kw, R, D),
+                    inplace=True)
+                self._next_iteration()
+                X_w = ret[0]
+                # 'b (c k) -> b k c' (:1611), padded to K chains by repeating the first ones (:1613-1615)
+                X_temp = X_w.reshape(B, c, Kw // c, D).permute(0, 2, 1, 3).contiguous()
+                if R > 0:
+                    needed = K - X_temp.shape[1]
+                    X_temp = torch.cat([X_temp, X_temp[:, :needed]], dim=1)
+                for i in range(hp.num_k_per_cluster):
+                    X_temp_i = X_temp[:, :, i].contiguous()
+                    if hp.enqueue_allwarmup_samples_to_history or t == W - 1:
+                        history.enqueue_batch(X_temp_i)
+                    yield {'X': X_temp_i, 'acceptance': 1.0}
+                if R > 0 and t == W - 1:
+                    X_w = X_temp.permute(0, 2, 1, 3).reshape(B, c * X_temp.shape[1], D)
+            X = X_w.reshape(B, c, X_w.shape[1] // c, D).permute(0, 2, 1, 3)[:, :, 0].contiguous()
+
+        # ---- chain state after the warm-up (:1639-1662) ----
+        f = dict(device=dev, dtype=torch.float32)
+        st = dict(Z_old=torch.empty(B, K, Zd, **f), gen_old=torch.empty(B, K, P, **f),
+                  z_old_prior_lp=torch.empty(B, K, **f), x_old_lp=torch.empty(B, K, **f))
+        wk = dict(slots=torch.empty(B, K, device=dev, dtype=torch.int64),
+                  in_off=torch.empty(B, K, device=dev, dtype=torch.int64),
+                  use_prior=torch.empty(B, K, device=dev, dtype=torch.uint8), z_alt=torch.empty(B, K, Zd, **f),
+                  q=torch.empty(B, K, 2, Zd, **f), Z_new=torch.empty(B, K, Zd, **f), gen_new=torch.empty(B, K, P, **f),
+                  ll_new=torch.empty(B, K, **f), accepted=torch.empty(B, K, device=dev, dtype=torch.uint8),
+                  log_accept=torch.empty(B, K, **f))
+        L = _lib.lib()
+        h_enc = model.var_latent_network.packed().handle
+        h_dec = model.generator_network.packed().handle
+        stream = _lib.current_stream()
+
+        def cfg_now():
+            return _lib.cs_acmwg_cfg(B, K, D, Zd, latent, gen_dist, history.max_history_length,
+                                     max(history.tail_idx, 0), int(history.full), 0,
+                                     float(hp.prior_mixture_probability))
+
+        if hp.warmup_method == 'pseudo_gibbs':
+            if hp.num_pseudo_warmup_iterations < 1:
+                raise ValueError("pseudo_gibbs warm-up needs at least one iteration")
+            # the state is the last warm-up step's Z and generator parameters (:1653-1660); the
+            # masked log-likelihood only involves observed entries, which imputation never changes,
+            # so the value computed by that step's decoder launch is the one needed here
+            ws = engine.lair_workspace(model, B, K, 0, 1, dev)
+            st["Z_old"].copy_(ws.Z[0])
+            st["gen_old"].copy_(ws.gen[0])
+            st["x_old_lp"].copy_(ws.gen_ll[0])
+            _lib.check(L.cs_stdnormal_logprob_rows(_lib.ptr(st["Z_old"]), B * K, Zd, _lib.ptr(st["z_old_prior_lp"]),
+                                                   stream))
+        else:
+            eps = src.normal(B, K, Zd).to(dev).contiguous() if src is not None else None
+            bufs = _lib.make_acmwg_bufs(X=X, M=M8, eps_z=eps, q=wk["q"], **st)
+            rng = self._rng()
+            _lib.check(L.cs_acmwg_init_state(h_enc, h_dec, C.byref(cfg_now()), C.byref(bufs), C.byref(rng), stream))
+            self._next_iteration()
+        history.update_available_timesteps(None)
+
+        for t in range(hp.num_mwg_iterations):
+            d = {}
+            if src is not None:
+                bounds = torch.clamp(history.available_timesteps, min=1).cpu()
+                r = torch.empty(B, K, dtype=torch.int64)
+                for b in range(B):
+                    for k in range(K):
+                        r[b, k] = src.randint(int(bounds[b, k]))
+                d["r_hist"] = r.to(dev)
+                d["eps_z"] = src.normal(B, K, Zd).to(dev).contiguous()
+                if hp.prior_mixture_probability > 0.:
+                    d["z_prior"] = src.normal(B, K, Zd).to(dev).contiguous()
+                    d["u_prior"] = src.uniform(B, K).to(dev).contiguous()
+                d["u_accept"] = src.uniform(B, K).to(dev).contiguous()
+                d["eps_x"] = (src.uniform(B, K, D) if bern else src.normal(B, K, D)).to(dev).contiguous()
+            bufs = _lib.make_acmwg_bufs(X=X, M=M8, ring=history.history_queue, avail=history.available_timesteps,
+                                        **st, **wk, **d)
+            rng = self._rng()
+            _lib.check(L.cs_acmwg_step(h_enc, h_dec, C.byref(cfg_now()), C.byref(bufs), C.byref(rng), stream))
+            history.advance()
+            self._next_iteration()
+            yield {'X': X, 'Z': st["Z_old"], 'acceptance': wk["accepted"].float().mean(),
+                   '_accepted': wk["accepted"], '_slots': wk["slots"], '_log_accept': wk["log_accept"]}
+
+    # -- helpers --
+    def _pg_step_noclip(self, X, M, M8, draws):
+        """Pseudo-Gibbs warm-up step without the clipping / non-finite safety (:1553-1580)."""
+        import ctypes as C
+        B, K, D = X.shape
+        model = self.model
+        ws = engine.lair_workspace(model, B, K, 0, 1, X.device)
+        cfg = engine.lair_cfg(model, ws, weighting="smis", scheme="gr", method="multinomial", cluster_size=0,
+                              weight_alpha=None)
+        eps_z = draws["eps_z"].to(X.device, torch.float32).contiguous() if draws else None
+        bufs = _lib.make_bufs(X=X, M=M8, eps_z=eps_z, q=ws.q, Z=ws.Z, gen=ws.gen, gen_ll=ws.gen_ll)
+        rng = self._rng()
+        L = _lib.lib()
+        stq = _lib.current_stream()
+        _lib.check(L.cs_lair_encode(model.var_latent_network.packed().handle, C.byref(cfg), C.byref(bufs), stq))
+        _lib.check(L.cs_lair_decode(model.generator_network.packed().handle, C.byref(cfg), C.byref(bufs), C.byref(rng), stq))
+        engine.sample_impute(model, ws.gen, X, M8, K, eps=draws["eps_x"] if draws else None, rng=rng,
+                             stream_id=_lib.STREAM_X)
+        return X, ws.Z[0]

@@ -1,0 +1,101 @@
+"""GPU: counter-RNG mode of the engine, sharding invariance and the YAML driver end to end."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import assert_close, make_model, seeded_inputs
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_philox_uniforms_are_bit_exact_with_the_c_restatement():
+    from oracle import c_binding
+    from vae_conditional_sampling_amd import _lib
+    from vae_conditional_sampling_amd.sampling import engine
+    L = c_binding.load()
+    rng = _lib.make_rng(0x1234567890ABCDEF, 7, 1000)
+    dev = torch.device("cuda")
+    u64 = engine.rng_uniform64(rng, _lib.STREAM_URES, 33, 9, dev).cpu().numpy()
+    assert np.array_equal(u64, c_binding.uniform64_rows(L, 0x1234567890ABCDEF, _lib.STREAM_URES, 7, 1000, 33, 9))
+    u32 = engine.rng_uniform(rng, _lib.STREAM_UACC, 17, 5, dev).cpu().numpy()
+    assert np.array_equal(u32, c_binding.uniform_rows(L, 0x1234567890ABCDEF, _lib.STREAM_UACC, 7, 1000, 17, 5))
+    assert (u64 >= 0).all() and (u64 < 1).all() and (u32 > 0).all() and (u32 < 1).all()
+    n = engine.rng_normal(rng, _lib.STREAM_Z, 4096, 32, dev)
+    assert abs(float(n.mean())) < 0.02 and abs(float(n.std()) - 1.0) < 0.02
+
+
+def test_lair_counter_rng_mode_matches_oracle_on_the_same_draws():
+    """Without injected draws the kernels generate them (Philox).  The same numbers, dumped
+    through cs_rng_*, are fed to the oracle: every output must agree."""
+    from oracle import cs_oracle as O
+    from vae_conditional_sampling_amd import _lib
+    from vae_conditional_sampling_amd.sampling import engine
+    from vae_conditional_sampling_amd.sampling.vae_imputation import importance_resampling_gibbs_iteration
+    B, K, R, D, Zd, H = 96, 4, 1, 43, 32, 256
+    Kp = K + R
+    enc = O.make_resfc_weights(D, 2 * Zd, 2, H, 21)
+    dec = O.make_resfc_weights(Zd, 2 * D, 1, H, 22)
+    model = make_model(enc, dec)
+    X, M = seeded_inputs(B, K, D, 23)
+    off, it, seed = 500, 3, 99
+    rng = _lib.make_rng(seed, it, off)
+    out = importance_resampling_gibbs_iteration(model, X.cuda(), M.cuda(), 1, num_prior_replenish_proposals=R, rng=rng)
+    X_gpu, lw_gpu = out[0].clone(), out[7].clone()
+    ws = model._cs_workspaces[("lair", B, K, R, 1, "cuda:0")]
+    idx_gpu = ws.idx.cpu().clone()
+    dev = torch.device("cuda")
+    draws = {
+        "eps_z": engine.rng_normal(_lib.make_rng(seed, it, off * Kp), _lib.STREAM_Z, B * Kp, Zd, dev).reshape(1, B, Kp, Zd).cpu(),
+        "u_res": engine.rng_uniform64(_lib.make_rng(seed, it, off), _lib.STREAM_URES, B, Kp, dev).cpu(),
+        "eps_x": engine.rng_normal(_lib.make_rng(seed, it, off * K), _lib.STREAM_X, B * K, D, dev).reshape(B, K, D).cpu(),
+    }
+    o = O.lair_iteration(enc, dec, X, M, draws, num_prior_replenish_proposals=R)
+    assert_close(ws.Z, o["Z_imp"], "Z_imp")
+    assert_close(lw_gpu, o["log_weights"], "log_weights")
+    assert torch.equal(idx_gpu, o["idx_global"])
+    assert_close(X_gpu, o["X_new"], "X_new")
+
+    # sharding invariance: two half batches with their global offsets give the same result bit for bit
+    h = B // 2
+    o1 = importance_resampling_gibbs_iteration(model, X[:h].cuda(), M[:h].cuda(), 1, num_prior_replenish_proposals=R,
+                                               rng=_lib.make_rng(seed, it, off))[0].clone()
+    o2 = importance_resampling_gibbs_iteration(model, X[h:].cuda(), M[h:].cuda(), 1, num_prior_replenish_proposals=R,
+                                               rng=_lib.make_rng(seed, it, off + h))[0].clone()
+    assert torch.equal(torch.cat([o1, o2]), X_gpu)
+
+
+def test_yaml_driver_end_to_end_lair_and_acmwg(tmp_path):
+    from vae_conditional_sampling_amd import driver
+    common = ["data.synthetic_num_test=150", "data.num_first_datapoints_test=100", "data.batch_size=64",
+              f"trainer.default_root_dir={tmp_path}"]
+    cfg = driver.load_config(os.path.join(ROOT, "configs/uci_miniboone/sampling_u50/lair_k4_dmis_gr_mult_1replenish.yaml"),
+                             common + ["test_class.init_args.num_iterations=6"])
+    tester, outs = driver.run(cfg)
+    assert len(outs) == 2
+    f0 = np.load(os.path.join(tester.out_dir, "imputations_0.npz"))
+    assert f0["imputations"].shape == (7, 64, 4, 43) and f0["masks"].shape == (64, 1, 43)
+    assert f0["true_X"].shape == (64, 1, 43) and f0["data_idx"].shape == (64,)
+    obs = np.broadcast_to(f0["masks"], (64, 4, 43))
+    for t in range(7):  # observed entries never change
+        assert np.array_equal(f0["imputations"][t][obs], np.broadcast_to(f0["true_X"], (64, 4, 43))[obs])
+    assert np.isfinite(f0["imputations"]).all()
+    f1 = np.load(os.path.join(tester.out_dir, "irwg_imputations_after_final_resampling_1.npz"))
+    assert f1["imputations"].shape == (1, 36, 6 * 5, 43)
+    assert all(0 < e <= 5 for e in outs[0]["is_ess"])
+
+    cfg = driver.load_config(os.path.join(ROOT, "configs/uci_miniboone/sampling_u50/acmwg_k5_005prior_irwg_warmup.yaml"),
+                             common + ["test_class.init_args.num_pseudo_warmup_iterations=2",
+                                       "test_class.init_args.num_mwg_iterations=9"])
+    tester, outs = driver.run(cfg)
+    g0 = np.load(os.path.join(tester.out_dir, "imputations_0.npz"))
+    assert g0["imputations"].shape == (1 + 2 * 4 + 9, 64, 5, 43) and np.isfinite(g0["imputations"]).all()
+    acc = outs[0]["acceptance"]
+    assert len(acc) == 17 and all(0.0 <= a <= 1.0 for a in acc) and acc[0] == 1.0
+    # the device history evolved like the reference queue: only the last warm-up iteration's
+    # num_k_per_cluster imputations and the 9 MWG steps were enqueued (ring capacity 17)
+    assert not tester.history.full and tester.history.tail_idx == 4 + 9 - 1
+    av = tester.history.available_timesteps.cpu()
+    assert int(av.min()) >= 4 and int(av.max()) <= 4 + 9 - 1

@@ -1,0 +1,111 @@
+"""CPU: host-side logic around the kernels (no GPU calls): hyper-parameter capture, iteration
+counts, unsupported-option errors, YAML driver parsing, data module, sharding."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BASE_KW = dict(store_last_n_iterations=-1, store_every_n_iterations=1, imputation_metric_quantiles=[],
+               compute_f1_metric=False, compute_inv_f1_metric=False, compute_bin_accuracy_metric=False,
+               compute_rmse_metric=False, compute_ssim_metric=False, compute_latent_wass_metric=False,
+               imputation_fn="vae_samples", num_copies=4)
+
+
+def test_sampler_classes_capture_hyperparameters_like_lightning():
+    from vae_conditional_sampling_amd.sampling.test_step_vae_sampling import (
+        TestVAEAdaptiveCollapsedMetropolisWithinGibbs, TestVAELatentAdaptiveImportanceResampling)
+    s = TestVAELatentAdaptiveImportanceResampling(num_iterations=7, num_imp_samples=1, weighting_scheme="dmis",
+                                                  resampling_scheme="gr", resampling_method="multinomial",
+                                                  num_prior_replenish_proposals=1, **BASE_KW)
+    assert s.max_iterations == 7 and s.hparams.num_copies == 4 and s.hparams.resample_final_imps is False
+    assert s.hparams.num_prior_replenish_proposals == 1 and s.hparams.store_latents is False
+    a = TestVAEAdaptiveCollapsedMetropolisWithinGibbs(num_pseudo_warmup_iterations=100, num_mwg_iterations=2900,
+                                                      prior_mixture_probability=0.05, warmup_method="irwg",
+                                                      num_k_per_cluster=4, glr_cluster_size=5,
+                                                      num_prior_replenish_proposals=5, **BASE_KW)
+    assert a.max_iterations == 100 * 4 + 2900
+    b = TestVAEAdaptiveCollapsedMetropolisWithinGibbs(num_pseudo_warmup_iterations=10, num_mwg_iterations=5,
+                                                      prior_mixture_probability=0.0, **BASE_KW)
+    assert b.max_iterations == 15 and b.hparams.warmup_method == "pseudo_gibbs"
+    with pytest.raises(AssertionError):  # num_k_per_cluster + R/cluster must equal cluster (reference :1503)
+        TestVAEAdaptiveCollapsedMetropolisWithinGibbs(num_pseudo_warmup_iterations=1, num_mwg_iterations=1,
+                                                      prior_mixture_probability=0.0, warmup_method="irwg",
+                                                      num_k_per_cluster=3, glr_cluster_size=5,
+                                                      num_prior_replenish_proposals=5, **BASE_KW)
+
+
+def test_unsupported_options_raise_not_implemented():
+    from vae_conditional_sampling_amd.sampling.test_step_vae_sampling import TestVAELatentAdaptiveImportanceResampling
+    from vae_conditional_sampling_amd.sampling.vae_imputation import importance_resampling_gibbs_iteration
+    kw = dict(BASE_KW)
+    kw["compute_rmse_metric"] = True
+    s = TestVAELatentAdaptiveImportanceResampling(num_iterations=1, num_imp_samples=1, weighting_scheme="dmis",
+                                                  resampling_scheme="gr", resampling_method="multinomial", **kw)
+    with pytest.raises(NotImplementedError):
+        s.on_test_start()
+    s.skip_unimplemented_diagnostics = True
+    s.on_test_start()
+    X = torch.zeros(2, 2, 3); M = torch.ones(2, 1, 3, dtype=torch.bool)
+    for bad in (dict(resampling_scheme="lr"), dict(resampling_scheme="ir"), dict(weighting="nope"),
+                dict(resampling_method="residual"), dict(use_historical_proposals=True),
+                dict(var_proposal_temperature=0.5), dict(accept_reject_xm=True)):
+        with pytest.raises(NotImplementedError):
+            importance_resampling_gibbs_iteration(None, X, M, 1, **bad)
+
+
+def test_models_mirror_reference_state_dict_layout():
+    from vae_conditional_sampling_amd.models import DISTRIBUTION, VAE, ResidualFCNetwork
+    enc = ResidualFCNetwork(43, 64, 5, 256, dropout_probability=0.5, activation="relu")
+    dec = ResidualFCNetwork(32, 86, 2, 256)
+    vae = VAE(dec, "normal_with_eps", enc, DISTRIBUTION.normal_with_eps)
+    keys = set(vae.state_dict().keys())
+    assert "var_latent_network.initial_layer.weight" in keys
+    assert "var_latent_network.blocks.4.linear_layers.1.bias" in keys
+    assert "generator_network.final_layer.weight" in keys
+    assert vae.state_dict()["generator_network.final_layer.weight"].shape == (86, 256)
+    assert vae.hparams.generator_distribution is DISTRIBUTION.normal_with_eps and vae.latent_dim == 32
+    with pytest.raises(NotImplementedError):
+        ResidualFCNetwork(4, 4, 1, 64, use_layer_norm=True)
+    p = vae.split_params(torch.arange(12.).reshape(2, 6), 2)
+    assert p.shape == (2, 2, 3) and torch.equal(vae.join_params(p), torch.arange(12.).reshape(2, 6))
+
+
+def test_driver_config_and_data_module(tmp_path):
+    from vae_conditional_sampling_amd import driver
+    from vae_conditional_sampling_amd.data import MissingDataModule
+    cfg = driver.load_config(os.path.join(ROOT, "configs/uci_miniboone/sampling_u50/lair_k4_dmis_gr_mult_1replenish.yaml"),
+                             ["data.batch_size=128", "test_class.init_args.num_iterations=3"])
+    assert cfg["data"]["batch_size"] == 128 and cfg["test_class"]["init_args"]["num_iterations"] == 3
+    assert driver.construct_experiment_subdir(cfg).endswith("seed_m20220118_d20220118")
+    cls = driver.resolve_test_class(cfg["test_class"]["class_path"])
+    assert cls.__name__ == "TestVAELatentAdaptiveImportanceResampling"
+    tester = cls(**cfg["test_class"]["init_args"])
+    assert tester.max_iterations == 3
+    with pytest.raises(NotImplementedError):
+        driver.resolve_test_class("irwg.sampling.test_step_vae_sampling.TestVAEPseudoGibbs")
+    dm = MissingDataModule(**cfg["data"])
+    dm.setup("test")
+    X, M, I = dm.test_data
+    assert X.shape == (3000, 43) and M.dtype == torch.bool and I.dtype == torch.int64
+    assert M.any(dim=1).all()                      # fully-missing rows were filtered
+    assert abs(float((~M).float().mean()) - 0.5) < 0.02
+    batches = list(dm.test_dataloader())
+    assert len(batches) == len(dm) == 24 and batches[0][0].shape == (128, 43)
+    # sharding: contiguous blocks that tile the set, deterministic data regardless of world size
+    parts = []
+    for r in range(3):
+        d = MissingDataModule(**cfg["data"], rank=r, world_size=3)
+        d.setup("test")
+        parts.append(d.test_data[0])
+        assert d.shard_offset == sum(p.shape[0] for p in parts[:-1])
+    assert torch.equal(torch.cat(parts), X)
+
+
+def test_uniform_mask_has_exact_missing_count():
+    from vae_conditional_sampling_amd.data.missing_data_module import shard_range, uniform_missingness_mask
+    m = uniform_missingness_mask((100, 7), 0.5, torch.Generator().manual_seed(1))
+    assert int((~m).sum()) == 350
+    assert [shard_range(10, r, 4) for r in range(4)] == [(0, 3), (3, 6), (6, 8), (8, 10)]
+    assert shard_range(0, 0, 2) == (0, 0)

@@ -1,0 +1,79 @@
+"""CPU: the oracle restatement reproduces the golden vectors recorded from the reference.
+
+The fixtures under tests/golden/ were written by oracle/check_against_reference.py, which ran the
+reference package itself with a recorded draw tape (there the match is bitwise).  Here the same
+draws are replayed on whatever host runs the tests, so floats are compared to 1e-5 relative
+(torch's vectorised exp/log may differ by an ulp between CPU models) and indices exactly.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import cs_oracle as O
+from oracle import cs_oracle_samplers as S
+from tests.helpers import assert_close, load_golden, weights_from_fixture
+
+LAIR_CASES = ["lair_gr_mult_small", "lair_gr_mult_i2_lat", "lair_gr_mult_noreplenish", "lair_gr_syst",
+              "lair_glr_groups", "lair_miniboone_shape"]
+
+
+@pytest.mark.parametrize("name", LAIR_CASES)
+def test_oracle_lair_iteration(name):
+    fx = load_golden(name)
+    B, K, R, I, D, Zd, H, cluster, iters = [int(v) for v in fx["cfg"]]
+    enc, dec = weights_from_fixture(fx, "enc"), weights_from_fixture(fx, "dec")
+    X = torch.from_numpy(fx["X0"]); M = torch.from_numpy(fx["M"])
+    want_lat = bool(fx["resampled_latents"])
+    for t in range(iters):
+        draws = {k: torch.from_numpy(fx[f"t{t}_{k}"]) for k in ("eps_z", "u_res", "eps_x")}
+        if want_lat:
+            draws["u_res2"] = torch.from_numpy(fx[f"t{t}_u_res2"])
+        o = O.lair_iteration(enc, dec, X, M, draws, num_imp_samples=I, weighting=str(fx["weighting"]),
+                             resampling_scheme=str(fx["scheme"]), resampling_method=str(fx["method"]),
+                             glr_cluster_size=cluster or None, num_prior_replenish_proposals=R,
+                             return_resampled_latents=want_lat)
+        assert_close(o["log_weights"], fx[f"t{t}_log_weights"], "log_weights")
+        assert np.array_equal(o["idx_global"].numpy(), fx[f"t{t}_idx"])
+        assert_close(o["X_new"], fx[f"t{t}_X_new"], "X_new")
+        assert_close(o["norm_log_weights"], fx[f"t{t}_norm_log_weights"], "norm_log_weights")
+        assert_close(o["ess"], fx[f"t{t}_ess"], "ess", 1e-4)
+        if want_lat:
+            assert_close(o["latents_resampled"], fx[f"t{t}_latents_resampled"], "latents")
+        X = o["X_new"]
+
+
+@pytest.mark.parametrize("name", ["acmwg_irwg_warmup", "acmwg_pg_warmup", "acmwg_nowarmup_noprior"])
+def test_oracle_acmwg_sampler(name):
+    fx = load_golden(name)
+    B, K, D, Zd, H, W, T, nkpc, cluster, R = [int(v) for v in fx["cfg"]]
+    enc, dec = weights_from_fixture(fx, "enc"), weights_from_fixture(fx, "dec")
+    src = S.TapeSource(S.tape_from_npz_dict(fx))
+    outs = list(S.acmwg_sampler(enc, dec, torch.from_numpy(fx["X0"]), torch.from_numpy(fx["M"]), src,
+                                num_pseudo_warmup_iterations=W, num_mwg_iterations=T,
+                                prior_mixture_probability=float(fx["p"]), warmup_method=str(fx["warmup"]),
+                                num_k_per_cluster=nkpc or None, glr_cluster_size=cluster or None,
+                                num_prior_replenish_proposals=R))
+    assert src.pos == len(src.entries)
+    mwg = [o for o in outs if "accepted" in o]
+    assert np.array_equal(np.stack([o["accepted"].numpy() for o in mwg]), fx["accepted"])
+    assert np.array_equal(np.stack([o["slots"].numpy() for o in mwg]), fx["slots"])
+    for t, o in enumerate(outs):
+        assert_close(o["X"], fx["X_seq"][t], f"X[{t}]")
+
+
+@pytest.mark.parametrize("name", ["lair_sampler_final", "lair_sampler_final_n5"])
+def test_oracle_lair_sampler_final(name):
+    fx = load_golden(name)
+    B, K, R, D, Zd, H, T, n_final, freq = [int(v) for v in fx["cfg"]]
+    enc, dec = weights_from_fixture(fx, "enc"), weights_from_fixture(fx, "dec")
+    src = S.TapeSource(S.tape_from_npz_dict(fx))
+    M = torch.from_numpy(fx["M"])
+    outs = list(S.lair_sampler(enc, dec, torch.from_numpy(fx["X0"]), M, src, num_iterations=T,
+                               num_prior_replenish_proposals=R, prior_replenish_iteration_frequency=freq,
+                               store_latents=True, collect_proposals=True))
+    for t, o in enumerate(outs):
+        assert_close(o["X"], fx["X_seq"][t], f"X[{t}]")
+    idx, Zf, imps = S.lair_final_resample(dec, [o["Z_prop"] for o in outs], [o["log_weights"] for o in outs],
+                                          torch.from_numpy(fx["X_true"]), M, src, num_samples=n_final or None)
+    assert np.array_equal(idx.numpy(), fx["final_idx"])
+    assert_close(imps.unsqueeze(0), fx["final_imputations"], "final imputations")

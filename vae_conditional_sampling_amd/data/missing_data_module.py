@@ -1,0 +1,103 @@
+"""Test-split data module with the reference's batch contract.
+
+Counterpart of ``MissingDataModule`` (irwg/data/missing_data_module.py:187-470) restricted to
+what the sampling driver needs: ``setup('test')`` builds the test split, applies the
+missingness pattern, optionally drops fully-missing rows, appends the data index and keeps the
+first ``num_first_datapoints_test`` points; ``test_dataloader()`` yields
+``(X float32 [B,D], M bool [B,D] (True = observed), I int64 [B])`` in order (no shuffling).
+
+Datasets: a ``.npy`` file ``{data_root}/{dataset}/test.npy`` when present; otherwise, when
+``synthetic`` is true, seeded standard-normal data with the dataset's dimensionality (the UCI
+sets are standardised, irwg/data/uci_miniboone.py:44-53) -- the real data files are not
+distributed with this package.
+
+Sharding: ``rank`` / ``world_size`` split the (filtered, index-ordered) test set into
+contiguous blocks, one per process; ``shard_offset`` is the global index of the first local
+example and keys the counter RNG.
+"""
+import math
+import os
+
+import numpy as np
+import torch
+
+from ..utils.hparams import AttrDict
+
+DATASET_DIMS = {"uci_miniboone": 43, "uci_hepmass": 21, "uci_gas": 8, "uci_power": 6, "toy_grid2dmog4": 2}
+DATASET_TEST_SIZES = {"uci_miniboone": 3648, "uci_hepmass": 174987, "uci_gas": 105206, "uci_power": 204928,
+                      "toy_grid2dmog4": 14}
+
+
+def uniform_missingness_mask(shape, total_miss, rng):
+    """Exactly ``int(total_miss * N*D)`` missing cells placed by a random permutation of all
+    cells (irwg/data/uniform_missingness_provider.py:50-63).  True = observed."""
+    total = int(np.prod(shape))
+    mask = torch.ones(total, dtype=torch.bool)
+    mask[:int(total_miss * total)] = 0
+    perm = torch.randperm(total, generator=rng)
+    return mask[perm].reshape(*shape)
+
+
+def shard_range(n, rank, world_size):
+    """Contiguous block [lo, hi) of rank `rank` when n examples are split over world_size ranks
+    (blocks differ by at most one example)."""
+    base, rem = divmod(n, world_size)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+class MissingDataModule:
+    def __init__(self, dataset, batch_size, missingness="uniform", total_miss_test=0.0, setup_seed=0,
+                 data_root="./data", num_first_datapoints_test=None, filter_fully_missing_test=False,
+                 synthetic=False, synthetic_num_test=None, rank=0, world_size=1, **unused):
+        self.hparams = AttrDict(dataset=dataset, batch_size=batch_size, missingness=missingness,
+                                total_miss_test=total_miss_test, setup_seed=setup_seed, data_root=data_root,
+                                num_first_datapoints_test=num_first_datapoints_test,
+                                filter_fully_missing_test=filter_fully_missing_test, synthetic=synthetic,
+                                synthetic_num_test=synthetic_num_test, rank=rank, world_size=world_size, **unused)
+        self.model = None
+
+    def set_model(self, model):
+        self.model = model
+
+    def setup(self, stage="test"):
+        if stage != "test":
+            raise NotImplementedError(f"{stage=} is not implemented.")
+        hp = self.hparams
+        rng = torch.Generator().manual_seed(int(hp.setup_seed))
+        rng_dataset = torch.Generator().manual_seed(int(hp.setup_seed * 2.33 / 2))
+        path = os.path.join(hp.data_root, hp.dataset, "test.npy")
+        if os.path.exists(path):
+            X = torch.from_numpy(np.load(path, allow_pickle=False).astype(np.float32))
+        elif hp.synthetic:
+            if hp.dataset not in DATASET_DIMS:
+                raise NotImplementedError(f"unknown dataset {hp.dataset!r}")
+            n = hp.synthetic_num_test or DATASET_TEST_SIZES[hp.dataset]
+            X = torch.randn(n, DATASET_DIMS[hp.dataset], generator=rng_dataset)
+        else:
+            raise FileNotFoundError(f"{path} not found (set data.synthetic: true for shape-faithful synthetic data)")
+        self.test_data_core = AttrDict(data=X, data_min=X.min(0)[0].numpy(), data_max=X.max(0)[0].numpy())
+        if str(hp.missingness).split(".")[-1] != "uniform":
+            raise NotImplementedError(f"missingness {hp.missingness!r} (only 'uniform')")
+        M = uniform_missingness_mask(tuple(X.shape), hp.total_miss_test, rng)
+        I = torch.arange(X.shape[0], dtype=torch.int64)
+        if hp.filter_fully_missing_test:
+            keep = M.any(dim=1)
+            X, M, I = X[keep], M[keep], I[keep]
+        if hp.num_first_datapoints_test is not None:
+            n = min(X.shape[0], int(hp.num_first_datapoints_test))
+            X, M, I = X[:n], M[:n], I[:n]
+        self.num_test_total = X.shape[0]
+        lo, hi = shard_range(X.shape[0], hp.rank, hp.world_size)
+        self.shard_offset = lo
+        self.test_data = (X[lo:hi].contiguous(), M[lo:hi].contiguous(), I[lo:hi].contiguous())
+        print("Test data size:", self.num_test_total, f"(this rank: {hi - lo})")
+
+    def __len__(self):
+        return math.ceil(self.test_data[0].shape[0] / self.hparams.batch_size)
+
+    def test_dataloader(self):
+        X, M, I = self.test_data
+        bs = int(self.hparams.batch_size)
+        for lo in range(0, X.shape[0], bs):
+            yield X[lo:lo + bs], M[lo:lo + bs], I[lo:lo + bs]

@@ -38,16 +38,33 @@ typedef __attribute__((address_space(3))) float lds_float;
 // ----------------------------------------------------------------------------------------
 template <int NTN>
 __device__ __forceinline__ void stage_mma(f32x16 (&acc)[NTN], const f32x16& bop, const lds_f32x4* sb, int lane) {
+  // Software-pipelined: the weight fragments of group g+1 (two n-tiles x 4 k-steps) are read
+  // from LDS while the 8 MFMAs of group g execute; sched_barrier keeps that order.
+  constexpr int NG = 4 * NTN / 2;  // groups per stage
+  static_assert(NTN % 2 == 0, "n-tiles are processed in pairs");
+  f32x4 w0 = sb[0 * 64 + lane], w1 = sb[1 * 64 + lane];
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-#pragma unroll
-    for (int nt = 0; nt < NTN; ++nt) {
-      const f32x4 w = sb[(q * NTN + nt) * 64 + lane];
-      acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.x, bop[4 * q + 0], acc[nt], 0, 0, 0);
-      acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.y, bop[4 * q + 1], acc[nt], 0, 0, 0);
-      acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.z, bop[4 * q + 2], acc[nt], 0, 0, 0);
-      acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.w, bop[4 * q + 3], acc[nt], 0, 0, 0);
+  for (int g = 0; g < NG; ++g) {
+    const int q = (2 * g) / NTN, nt = (2 * g) % NTN;
+    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0.x, bop[4 * q + 0], acc[nt], 0, 0, 0);
+    acc[nt + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1.x, bop[4 * q + 0], acc[nt + 1], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    // issued behind two MFMAs (128 cycles of matrix work are queued), landed long before the
+    // next group's first MFMA: the wait there is free
+    f32x4 n0 = w0, n1 = w1;
+    if (g + 1 < NG) {
+      n0 = sb[(2 * (g + 1)) * 64 + lane];
+      n1 = sb[(2 * (g + 1) + 1) * 64 + lane];
     }
+    __builtin_amdgcn_sched_barrier(0);
+    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0.y, bop[4 * q + 1], acc[nt], 0, 0, 0);
+    acc[nt + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1.y, bop[4 * q + 1], acc[nt + 1], 0, 0, 0);
+    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0.z, bop[4 * q + 2], acc[nt], 0, 0, 0);
+    acc[nt + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1.z, bop[4 * q + 2], acc[nt + 1], 0, 0, 0);
+    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0.w, bop[4 * q + 3], acc[nt], 0, 0, 0);
+    acc[nt + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1.w, bop[4 * q + 3], acc[nt + 1], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    w0 = n0; w1 = n1;
   }
 }
 
@@ -63,6 +80,23 @@ __device__ __forceinline__ void load_bias(f32x16 (&acc)[NTN], const lds_float* l
     }
   }
 }
+// The activations live in the accumulator registers (AGPRs) from the MFMA that produces them to
+// the MFMAs that consume them as B operands.  VALU instructions cannot address AGPRs, so the
+// elementwise steps go through one scratch VGPR per element, in place, and the "+a" constraint
+// keeps the value's home in the accumulator file (otherwise the compiler keeps a second, VGPR
+// copy of every activation and runs out of registers).
+__device__ __forceinline__ float relu_acc(float x) {
+  float t;
+  asm volatile("v_accvgpr_read_b32 %1, %0\n\tv_max_f32 %1, 0, %1\n\tv_accvgpr_write_b32 %0, %1" : "+a"(x), "=&v"(t));
+  return x;
+}
+__device__ __forceinline__ float add_acc(float x, float b) {
+  float t;
+  asm volatile("v_accvgpr_read_b32 %1, %0\n\tv_add_f32 %1, %1, %2\n\tv_accvgpr_write_b32 %0, %1"
+               : "+a"(x), "=&v"(t)
+               : "v"(b));
+  return x;
+}
 template <int NTN>
 __device__ __forceinline__ void add_bias(f32x16 (&acc)[NTN], const lds_float* lb, int h) {
 #pragma unroll
@@ -70,17 +104,21 @@ __device__ __forceinline__ void add_bias(f32x16 (&acc)[NTN], const lds_float* lb
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const f32x4 b = *(const lds_f32x4*)(lb + 32 * nt + 8 * g + 4 * h);
-      acc[nt][4 * g + 0] += b.x; acc[nt][4 * g + 1] += b.y;
-      acc[nt][4 * g + 2] += b.z; acc[nt][4 * g + 3] += b.w;
+      acc[nt][4 * g + 0] = add_acc(acc[nt][4 * g + 0], b.x);
+      acc[nt][4 * g + 1] = add_acc(acc[nt][4 * g + 1], b.y);
+      acc[nt][4 * g + 2] = add_acc(acc[nt][4 * g + 2], b.z);
+      acc[nt][4 * g + 3] = add_acc(acc[nt][4 * g + 3], b.w);
     }
   }
+  asm volatile("s_nop 7" ::: "memory");  // accvgpr_write -> MFMA operand wait states
 }
 template <int NTN>
 __device__ __forceinline__ void relu_tiles(f32x16 (&acc)[NTN]) {
 #pragma unroll
   for (int nt = 0; nt < NTN; ++nt)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[nt][r] = fmaxf(acc[nt][r], 0.0f);
+    for (int r = 0; r < 16; ++r) acc[nt][r] = relu_acc(acc[nt][r]);
+  asm volatile("s_nop 7" ::: "memory");
 }
 
 // ----------------------------------------------------------------------------------------

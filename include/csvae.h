@@ -237,6 +237,10 @@ int cs_rng_normal(const cs_rng* rng, uint32_t stream_id, int64_t rows, int32_t c
 int cs_rng_uniform(const cs_rng* rng, uint32_t stream_id, int64_t rows, int32_t cols, float* out, void* stream);
 int cs_rng_uniform64(const cs_rng* rng, uint32_t stream_id, int64_t rows, int32_t cols, double* out, void* stream);
 
+/* Profiling hook (no counterpart in the reference): when buf != NULL every fused-MLP launch
+ * writes 16 clock stamps per 32-row tile into buf (device memory, 16*ceil(rows/32) int64). */
+int cs_debug_set_trace(long long* buf);
+
 #ifdef __cplusplus
 }
 #endif

@@ -54,6 +54,7 @@ struct CsMlpArgs {
   float* gen_ll;     // [rows]
   const float* X;    // [B,K,D]
   const uint8_t* M;  // [B,D]
+  long long* dbg;    // optional per-wave timestamps (tools/bench_mlp.py --trace)
 };
 
 int cs_mlp_launch(const CsMlpArgs& a, hipStream_t stream);

@@ -27,6 +27,7 @@
 //   * accumulators start from the bias (residual layer: from h + b2).
 #include "cs_mlp.h"
 
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -36,35 +37,50 @@ typedef __attribute__((address_space(3))) f32x4 lds_f32x4;
 typedef __attribute__((address_space(3))) float lds_float;
 
 // ----------------------------------------------------------------------------------------
-template <int NTN>
-__device__ __forceinline__ void stage_mma(f32x16 (&acc)[NTN], const f32x16& bop, const lds_f32x4* sb, int lane) {
-  // Software-pipelined: the weight fragments of group g+1 (two n-tiles x 4 k-steps) are read
-  // from LDS while the 8 MFMAs of group g execute; sched_barrier keeps that order.
+// One stage = one k-tile (32 input features) of one layer: 4*NTN weight fragments of 1 KB in the
+// LDS slot `sb`, 16*NTN MFMAs per wavefront.
+//   * fragments are read two at a time (8 MFMAs' worth) into one of two register sets, behind the
+//     first two MFMAs of the preceding group, so the LDS latency is covered by matrix work and
+//     no register is rewritten while an MFMA that reads it is in flight;
+//   * the global->LDS copies of the NEXT stage (RPS x global_load_lds_dwordx4 per thread, 1 KB
+//     per wave-instruction) are spread over the groups: issued back to back at the stage start
+//     they cost ~64 cycles of matrix-pipe idle each, interleaved ~20;
+//   * sched_barrier pins that order.
+//   * `side(g, NG)` is a hook for work placed inside the MFMA stream (unused in production).
+template <int NTN, int RPS, int NTHR, class Side>
+__device__ __forceinline__ void stage_mma(f32x16 (&acc)[NTN], const f32x16& bop, const lds_f32x4* sb, int lane,
+                                          const f32x4* pf_src, lds_f32x4* pf_dst, Side side) {
   constexpr int NG = 4 * NTN / 2;  // groups per stage
   static_assert(NTN % 2 == 0, "n-tiles are processed in pairs");
-  f32x4 w0 = sb[0 * 64 + lane], w1 = sb[1 * 64 + lane];
+  f32x4 w[2][2];
+  w[0][0] = sb[0 * 64 + lane];
+  w[0][1] = sb[1 * 64 + lane];
 #pragma unroll
   for (int g = 0; g < NG; ++g) {
     const int q = (2 * g) / NTN, nt = (2 * g) % NTN;
-    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0.x, bop[4 * q + 0], acc[nt], 0, 0, 0);
-    acc[nt + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1.x, bop[4 * q + 0], acc[nt + 1], 0, 0, 0);
+    const int c = g & 1, n = c ^ 1;
+    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[c][0].x, bop[4 * q + 0], acc[nt], 0, 0, 0);
+    acc[nt + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[c][1].x, bop[4 * q + 0], acc[nt + 1], 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
-    // issued behind two MFMAs (128 cycles of matrix work are queued), landed long before the
-    // next group's first MFMA: the wait there is free
-    f32x4 n0 = w0, n1 = w1;
     if (g + 1 < NG) {
-      n0 = sb[(2 * (g + 1)) * 64 + lane];
-      n1 = sb[(2 * (g + 1) + 1) * 64 + lane];
+      w[n][0] = sb[(2 * (g + 1)) * 64 + lane];
+      w[n][1] = sb[(2 * (g + 1) + 1) * 64 + lane];
     }
+#pragma unroll
+    for (int r = g * RPS / NG; r < (g + 1) * RPS / NG; ++r)
+      __builtin_amdgcn_global_load_lds(GLB_PTR(pf_src + r * NTHR),
+                                       (__attribute__((address_space(3))) void*)(pf_dst + r * NTHR), 16, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
-    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0.y, bop[4 * q + 1], acc[nt], 0, 0, 0);
-    acc[nt + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1.y, bop[4 * q + 1], acc[nt + 1], 0, 0, 0);
-    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0.z, bop[4 * q + 2], acc[nt], 0, 0, 0);
-    acc[nt + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1.z, bop[4 * q + 2], acc[nt + 1], 0, 0, 0);
-    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0.w, bop[4 * q + 3], acc[nt], 0, 0, 0);
-    acc[nt + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1.w, bop[4 * q + 3], acc[nt + 1], 0, 0, 0);
+    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[c][0].y, bop[4 * q + 1], acc[nt], 0, 0, 0);
+    acc[nt + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[c][1].y, bop[4 * q + 1], acc[nt + 1], 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
-    w0 = n0; w1 = n1;
+    side(g, NG);
+    __builtin_amdgcn_sched_barrier(0);
+    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[c][0].z, bop[4 * q + 2], acc[nt], 0, 0, 0);
+    acc[nt + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[c][1].z, bop[4 * q + 2], acc[nt + 1], 0, 0, 0);
+    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[c][0].w, bop[4 * q + 3], acc[nt], 0, 0, 0);
+    acc[nt + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[c][1].w, bop[4 * q + 3], acc[nt + 1], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 
@@ -121,15 +137,34 @@ __device__ __forceinline__ void relu_tiles(f32x16 (&acc)[NTN]) {
   asm volatile("s_nop 7" ::: "memory");
 }
 
+// Slice g of ng of a 16-register tile: elements [16g/ng, 16(g+1)/ng).
+__device__ __forceinline__ void relu_slice(f32x16& t, int g, int ng) {
+#pragma unroll
+  for (int r = 16 * g / ng; r < 16 * (g + 1) / ng; ++r) t[r] = relu_acc(t[r]);
+}
+// lb_tile: bias of this tile's 32 features; register r of lane half h holds feature 8(r>>2)+4h+(r&3)
+__device__ __forceinline__ void addb_slice(f32x16& t, const lds_float* lb_tile, int h, int g, int ng) {
+#pragma unroll
+  for (int r = 16 * g / ng; r < 16 * (g + 1) / ng; ++r) t[r] = add_acc(t[r], lb_tile[8 * (r >> 2) + 4 * h + (r & 3)]);
+}
+__device__ __forceinline__ void setb_slice(f32x16& t, const lds_float* lb_tile, int h, int g, int ng) {
+#pragma unroll
+  for (int r = 16 * g / ng; r < 16 * (g + 1) / ng; ++r) t[r] = lb_tile[8 * (r >> 2) + 4 * h + (r & 3)];
+}
+// wait states between an MFMA's result write and a VALU read of it inside an asm statement
+#define CS_MFMA_RESULT_NOPS() asm volatile("s_nop 15\n\ts_nop 7" ::: "memory")
+
 // ----------------------------------------------------------------------------------------
-template <int NT, int NTO>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+template <int NT, int NTO, int WAVES>
+__global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(1, 1)))
 cs_mlp_kernel(const CsMlpArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int STAGE_F4 = 4 * NT * 64;   // float4 per hidden-layer stage
   constexpr int OSTAGE_F4 = 4 * NTO * 64; // float4 per output-layer stage
   constexpr int SLOT_F4 = STAGE_F4 > OSTAGE_F4 ? STAGE_F4 : OSTAGE_F4;  // ring slot
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = blockDim.x;
+  constexpr int nthr = 64 * WAVES;
+  constexpr int RPS = SLOT_F4 / nthr;  // global->LDS copies per thread per stage
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = lane >> 5, j = lane & 31;
   const int nl = 2 * a.net.nb + 2;
   const int bst = a.net.bias_stride;
@@ -138,24 +173,36 @@ cs_mlp_kernel(const CsMlpArgs a) {
 
   const int64_t row = ((int64_t)blockIdx.x * (nthr >> 6) + wave) * 32 + j;
   const bool rvalid = row < a.rows;
+  int dbg_i = 0;
+#define CS_STAMP()                                                                         \
+  do {                                                                                     \
+    if (a.dbg && lane == 0) a.dbg[(row >> 5) * 16 + (dbg_i < 15 ? dbg_i : 15)] = clock64(); \
+    ++dbg_i;                                                                               \
+  } while (0)
+  CS_STAMP();
 
   // ---- operand-stream prefetch machinery ----
   const f32x4* gp = a.net.wstream;
   int par = 0;
   const lds_f32x4* sb = ring;
-  auto prefetch = [&](const f32x4* src, lds_f32x4* dst) {
-    for (int off = 0; off < SLOT_F4; off += nthr)
-      __builtin_amdgcn_global_load_lds(GLB_PTR(src + off + tid), (__attribute__((address_space(3))) void*)(dst + off + (wave << 6)), 16, 0, 0);
-  };
-  prefetch(gp, ring);
+  const f32x4* pf_src = gp + tid;           // this thread's source of the next slot
+  lds_f32x4* pf_dst = ring + (wave << 6);   // this wave's destination in the next slot
+#pragma unroll
+  for (int r = 0; r < RPS; ++r)             // stage 0
+    __builtin_amdgcn_global_load_lds(GLB_PTR(pf_src + r * nthr), (__attribute__((address_space(3))) void*)(pf_dst + r * nthr),
+                                     16, 0, 0);
   for (int i = tid; i < nl * bst; i += nthr) lbias[i] = a.net.bias[i];
 
+  // Enter the next stage: its slot has landed (own copies waited for, then the barrier covers
+  // the other waves' copies and their reads of the slot about to be overwritten); point the
+  // prefetch at the stage after it.
 #define CS_NEXT_STAGE(CUR_F4)                                   \
   do {                                                          \
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            \
     __syncthreads();                                            \
     gp += (CUR_F4);                                             \
-    prefetch(gp, ring + (par ^ 1) * SLOT_F4);                   \
+    pf_src = gp + tid;                                          \
+    pf_dst = ring + (par ^ 1) * SLOT_F4 + (wave << 6);          \
     sb = ring + par * SLOT_F4;                                  \
     par ^= 1;                                                   \
   } while (0)
@@ -225,18 +272,25 @@ cs_mlp_kernel(const CsMlpArgs a) {
     }
   }
   __syncthreads();  // biases visible
+  CS_STAMP();
 
   // ---- first layer ----
+  // Elementwise work (bias, ReLU) runs between the layers, not inside the MFMA stream: on
+  // gfx950 a VALU instruction issued by the wave that owns the in-flight MFMA delays that wave's
+  // next MFMA by more than its own issue time (measured: interleaving was 5 % slower).
   f32x16 A[NT], T[NT];
+  auto no_side = [](int, int) {};
   load_bias<NT>(A, lbias, h);
 #pragma unroll
   for (int kt = 0; kt < 4; ++kt) {
     if (kt < a.net.nkt0) {
       CS_NEXT_STAGE(STAGE_F4);
-      stage_mma<NT>(A, xin[kt], sb, lane);
+      stage_mma<NT, RPS, nthr>(A, xin[kt], sb, lane, pf_src, pf_dst, no_side);
     }
   }
+  CS_MFMA_RESULT_NOPS();
   relu_tiles<NT>(A);
+  CS_STAMP();
 
   // ---- residual blocks ----
   for (int blk = 0; blk < a.net.nb; ++blk) {
@@ -244,16 +298,19 @@ cs_mlp_kernel(const CsMlpArgs a) {
 #pragma unroll
     for (int kt = 0; kt < NT; ++kt) {
       CS_NEXT_STAGE(STAGE_F4);
-      stage_mma<NT>(T, A[kt], sb, lane);
+      stage_mma<NT, RPS, nthr>(T, A[kt], sb, lane, pf_src, pf_dst, no_side);
     }
+    CS_MFMA_RESULT_NOPS();
     relu_tiles<NT>(T);
     add_bias<NT>(A, lbias + (2 + 2 * blk) * bst, h);
 #pragma unroll
     for (int kt = 0; kt < NT; ++kt) {
       CS_NEXT_STAGE(STAGE_F4);
-      stage_mma<NT>(A, T[kt], sb, lane);
+      stage_mma<NT, RPS, nthr>(A, T[kt], sb, lane, pf_src, pf_dst, no_side);
     }
+    CS_MFMA_RESULT_NOPS();
     relu_tiles<NT>(A);
+    CS_STAMP();
   }
 
   // ---- output layer ----
@@ -262,10 +319,11 @@ cs_mlp_kernel(const CsMlpArgs a) {
 #pragma unroll
   for (int kt = 0; kt < NT; ++kt) {
     CS_NEXT_STAGE(OSTAGE_F4);
-    stage_mma<NTO>(O, A[kt], sb, lane);
+    stage_mma<NTO, RPS, nthr>(O, A[kt], sb, lane, pf_src, pf_dst, no_side);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the trailing prefetch
 #undef CS_NEXT_STAGE
+  CS_STAMP();
 
   // ---- epilogues ----
   const int tph = a.net.tph;
@@ -284,6 +342,7 @@ cs_mlp_kernel(const CsMlpArgs a) {
         }
       }
     }
+    CS_STAMP();
     return;
   }
   // paired (first-half, second-half) epilogues: tile t pairs with tile t + tph
@@ -313,6 +372,7 @@ cs_mlp_kernel(const CsMlpArgs a) {
         for (int t = h; t < (a.Kp - a.K) * 2 * Zd; t += 2) qp[t] = ((t / Zd) & 1) ? 1.0f : 0.0f;
       }
     }
+    CS_STAMP();
     return;
   }
   // CS_MLP_DEC
@@ -363,32 +423,49 @@ cs_mlp_kernel(const CsMlpArgs a) {
     }
     ll += __shfl_xor(ll, 32);
     if (want_ll && rvalid && h == 0) a.gen_ll[row] = ll;
+    CS_STAMP();
   }
 }
 
 // ----------------------------------------------------------------------------------------
-template <int NT, int NTO>
-static int launch_t(const CsMlpArgs& a, hipStream_t stream) {
-  // small batches: one wavefront per workgroup so that more CUs take part
+template <int NT, int NTO, int WAVES>
+static int launch_w(const CsMlpArgs& a, hipStream_t stream) {
   const int64_t tiles = (a.rows + 31) / 32;
-  const int waves = tiles >= 4 * 256 ? 4 : (tiles >= 2 * 256 ? 2 : 1);
-  const int64_t grid = (tiles + waves - 1) / waves;
+  const int64_t grid = (tiles + WAVES - 1) / WAVES;
   const int nl = 2 * a.net.nb + 2;
   const size_t bias_bytes = (((size_t)nl * a.net.bias_stride * 4 + 1023) & ~(size_t)1023);
   const size_t lds = bias_bytes + 2 * (size_t)(4 * (NT > NTO ? NT : NTO) * 64) * 16;
   CS_REQUIRE(lds <= 160 * 1024, "network does not fit the LDS budget");
   static bool attr_set = false;
   if (!attr_set) {
-    CS_HIP(hipFuncSetAttribute((const void*)cs_mlp_kernel<NT, NTO>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    CS_HIP(hipFuncSetAttribute((const void*)cs_mlp_kernel<NT, NTO, WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                160 * 1024));
     attr_set = true;
   }
-  hipLaunchKernelGGL((cs_mlp_kernel<NT, NTO>), dim3((unsigned)grid), dim3(64 * waves), lds, stream, a);
+  hipLaunchKernelGGL((cs_mlp_kernel<NT, NTO, WAVES>), dim3((unsigned)grid), dim3(64 * WAVES), lds, stream, a);
   CS_HIP(hipGetLastError());
   return CS_OK;
 }
 
-int cs_mlp_launch(const CsMlpArgs& a, hipStream_t stream) {
+template <int NT, int NTO>
+static int launch_t(const CsMlpArgs& a, hipStream_t stream) {
+  // small batches: one wavefront per workgroup so that more CUs take part
+  const int64_t tiles = (a.rows + 31) / 32;
+  return tiles >= 4 * 256 ? launch_w<NT, NTO, 4>(a, stream) : launch_w<NT, NTO, 1>(a, stream);
+}
+
+static long long* g_trace = nullptr;
+// Profiling hook: when set, every fused-MLP launch writes 16 clock64() stamps per wavefront
+// (row tile) into buf: start, after prologue, after the first layer, after each block, after
+// the output layer, end.  buf must hold 16 * ceil(rows/32) entries.  NULL disables it.
+extern "C" int cs_debug_set_trace(long long* buf) {
+  g_trace = buf;
+  return CS_OK;
+}
+
+int cs_mlp_launch(const CsMlpArgs& a_in, hipStream_t stream) {
+  CsMlpArgs a = a_in;
+  a.dbg = g_trace;
   if (a.rows <= 0) return CS_OK;
   const int nt = a.net.nt, nto = a.net.nto;
   CS_REQUIRE(a.rows < ((int64_t)1 << 31) * 32, "too many rows");

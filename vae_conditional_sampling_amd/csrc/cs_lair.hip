@@ -23,6 +23,7 @@ struct CsResampleArgs {
   int Kp, S, G, c;       // resampling groups
   int mixG, mixc;        // mixture groups (dmis: 1,K'; within groups: G,c; smis: K',1)
   int lds_per_wave;      // floats
+  int E;                 // examples per wavefront
 };
 
 __device__ __forceinline__ float wave_max(float v) {
@@ -44,43 +45,79 @@ __device__ __forceinline__ float wave_logsumexp(float x, bool in) {
   return logf(s) + m;
 }
 
-__global__ void __launch_bounds__(256) cs_lair_resample_kernel(const CsResampleArgs a) {
-  extern __shared__ float lds_all[];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int64_t b = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave;
-  const bool valid = b < a.cfg.B;
+// E = floor(64/S) examples share a wavefront: lane = e*S + s.  Reductions over the proposals of
+// one example are loops of wave shuffles over its S lanes (S is small: 5..25 in the
+// configurations), so every lane does useful work.
+__global__ void __launch_bounds__(64) cs_lair_resample_kernel(const CsResampleArgs a) {
+  extern __shared__ float lds[];
+  const int lane = threadIdx.x;
   const int B = a.cfg.B, K = a.cfg.K, D = a.cfg.D, Zd = a.cfg.Zd, I = a.cfg.I;
-  const int Kp = a.Kp, S = a.S, G = a.G, c = a.c;
-  float* lds = lds_all + (size_t)wave * a.lds_per_wave;
-  float* l_loc = lds;                 // [Kp*Zd]
-  float* l_2var = l_loc + Kp * Zd;    // [Kp*Zd]  2*scale^2
-  float* l_logs = l_2var + Kp * Zd;   // [Kp*Zd]  log(scale)
-  float* l_z = l_logs + Kp * Zd;      // [S*(Zd+1)]
-  int* l_idx = (int*)(l_z + S * (Zd + 1));  // [2*Kp] resampled global indices (two draws)
+  const int Kp = a.Kp, S = a.S, G = a.G, c = a.c, E = a.E;
+  const int64_t b0 = (int64_t)blockIdx.x * E;            // first example of this wave
+  const int ne = (int)((B - b0) < E ? (B - b0) : E);     // examples present
+  float* l_loc = lds;                      // [E][Kp*Zd]
+  float* l_2var = l_loc + E * Kp * Zd;     // [E][Kp*Zd]  1/(2*scale^2)
+  float* l_logs = l_2var + E * Kp * Zd;    // [E][Kp*Zd]  log(scale)
+  float* l_z = l_logs + E * Kp * Zd;       // [E][S][Zd+1]
+  int* l_idx = (int*)(l_z + E * S * (Zd + 1));  // [E][2*Kp] resampled global indices (two draws)
 
-  if (valid) {
-    const float* qb = a.b.q + b * Kp * 2 * Zd;
-    for (int t = lane; t < Kp * Zd; t += 64) {
-      const int j = t / Zd, d = t - j * Zd;
-      const float loc = qb[j * 2 * Zd + d], sc = qb[j * 2 * Zd + Zd + d];
+  {
+    const float* qb = a.b.q + b0 * Kp * 2 * Zd;
+    for (int t = lane; t < ne * Kp * Zd; t += 64) {
+      const int ej = t / Zd, d = t - ej * Zd;  // ej = e*Kp + j
+      const float loc = qb[ej * 2 * Zd + d], sc = qb[ej * 2 * Zd + Zd + d];
       l_loc[t] = loc;
-      l_2var[t] = 2.0f * (sc * sc);
+      l_2var[t] = 1.0f / (2.0f * (sc * sc));
       l_logs[t] = logf(sc);
     }
-    for (int t = lane; t < S * Zd; t += 64) {
-      const int s = t / Zd, d = t - s * Zd;
+    for (int t = lane; t < ne * S * Zd; t += 64) {
+      const int es = t / Zd, d = t - es * Zd;
+      const int e = es / S, s = es - e * S;
       const int i = s / Kp, kp = s - i * Kp;
-      l_z[s * (Zd + 1) + d] = a.b.Z[(((int64_t)i * B + b) * Kp + kp) * Zd + d];
+      l_z[es * (Zd + 1) + d] = a.b.Z[(((int64_t)i * B + b0 + e) * Kp + kp) * Zd + d];
     }
   }
   __syncthreads();
 
-  const bool act = valid && lane < S;
-  const int s = lane;
-  const int i_s = act ? s / Kp : 0, kp_s = act ? s - i_s * Kp : 0;
-  float lw = -INFINITY;
+  const int e_l = lane / S;                 // example slot of this lane
+  const int s = lane - e_l * S;             // proposal
+  const bool act = e_l < ne;                // (lanes >= E*S have e_l >= E >= ne)
+  const int base = act ? e_l * S : 0;       // first lane of this example
+  const int64_t b = b0 + e_l;
+  const int i_s = s / Kp, kp_s = s - i_s * Kp;
+  const int g_s = kp_s % G, cc_s = kp_s / G;
+  const int li_s = i_s * c + cc_s;          // position inside the resampling group, '(i c)' order
+
+  // reductions over the lanes of this example (optionally only its resampling group)
+  auto seg_max = [&](float x, bool grouped) {
+    float m = -INFINITY;
+    for (int jj = 0; jj < S; ++jj) {
+      const float v = __shfl(x, base + jj);
+      if (!grouped || (jj % Kp) % G == g_s) m = fmaxf(m, v);
+    }
+    return m;
+  };
+  auto seg_sum = [&](float x, bool grouped) {
+    float t = 0.0f;
+    for (int jj = 0; jj < S; ++jj) {
+      const float v = __shfl(x, base + jj);
+      if (!grouped || (jj % Kp) % G == g_s) t += v;
+    }
+    return t;
+  };
+  // torch.logsumexp: max (0 when not finite), log(sum(exp(x - max))) + max
+  auto seg_lse = [&](float x, bool grouped) {
+    float m = seg_max(x, grouped);
+    if (!(fabsf(m) < INFINITY)) m = 0.0f;
+    return logf(seg_sum(expf(x - m), grouped)) + m;
+  };
+
+  float lw = 0.0f;
   if (act) {
-    const float* z = l_z + s * (Zd + 1);
+    const float* z = l_z + (e_l * S + s) * (Zd + 1);
+    const float* qloc = l_loc + e_l * Kp * Zd;
+    const float* q2v = l_2var + e_l * Kp * Zd;
+    const float* qls = l_logs + e_l * Kp * Zd;
     float pl = 0.0f;
     for (int d = 0; d < Zd; ++d) pl += cs_stdnormal_logpdf(z[d]);
     // mixture components of this proposal: j = gm + mixG*cc, cc < mixc
@@ -89,8 +126,8 @@ __global__ void __launch_bounds__(256) cs_lair_resample_kernel(const CsResampleA
     if (a.cfg.weighting == CS_W_SMIS) {
       float cj = 0.0f;
       for (int d = 0; d < Zd; ++d) {
-        const float df = z[d] - l_loc[kp_s * Zd + d];
-        cj += -(df * df) / l_2var[kp_s * Zd + d] - l_logs[kp_s * Zd + d] - CS_LOG_SQRT_2PI;
+        const float df = z[d] - qloc[kp_s * Zd + d];
+        cj += -(df * df) * q2v[kp_s * Zd + d] - qls[kp_s * Zd + d] - CS_LOG_SQRT_2PI;
       }
       ql = cj;
     } else {
@@ -99,8 +136,8 @@ __global__ void __launch_bounds__(256) cs_lair_resample_kernel(const CsResampleA
         const int j = gm + a.mixG * cc;
         float cj = 0.0f;
         for (int d = 0; d < Zd; ++d) {
-          const float df = z[d] - l_loc[j * Zd + d];
-          cj += -(df * df) / l_2var[j * Zd + d] - l_logs[j * Zd + d] - CS_LOG_SQRT_2PI;
+          const float df = z[d] - qloc[j * Zd + d];
+          cj += -(df * df) * q2v[j * Zd + d] - qls[j * Zd + d] - CS_LOG_SQRT_2PI;
         }
         m = fmaxf(m, cj);
       }
@@ -110,8 +147,8 @@ __global__ void __launch_bounds__(256) cs_lair_resample_kernel(const CsResampleA
         const int j = gm + a.mixG * cc;
         float cj = 0.0f;
         for (int d = 0; d < Zd; ++d) {
-          const float df = z[d] - l_loc[j * Zd + d];
-          cj += -(df * df) / l_2var[j * Zd + d] - l_logs[j * Zd + d] - CS_LOG_SQRT_2PI;
+          const float df = z[d] - qloc[j * Zd + d];
+          cj += -(df * df) * q2v[j * Zd + d] - qls[j * Zd + d] - CS_LOG_SQRT_2PI;
         }
         sum += expf(cj - m);
       }
@@ -125,16 +162,15 @@ __global__ void __launch_bounds__(256) cs_lair_resample_kernel(const CsResampleA
 
   // ---- ESS / perplexity over all S proposals (vae_imputation.py:708-719) ----
   {
-    const float lse = wave_logsumexp(lw, act);
-    const float lnw = lw - lse;
-    const float ess = expf(-wave_logsumexp(2.0f * lnw, act));
-    const float perp = expf(-wave_sum(act ? lnw * expf(lnw) : 0.0f));
+    const float lnw = lw - seg_lse(lw, false);
+    const float ess = expf(-seg_lse(2.0f * lnw, false));
+    const float perp = expf(-seg_sum(lnw * expf(lnw), false));
     float tess = ess;
     if (a.cfg.weight_alpha != 1.0f) {
-      const float tl = tlw - wave_logsumexp(tlw, act);
-      tess = expf(-wave_logsumexp(2.0f * tl, act));
+      const float tl = tlw - seg_lse(tlw, false);
+      tess = expf(-seg_lse(2.0f * tl, false));
     }
-    if (valid && lane == 0) {
+    if (act && s == 0) {
       a.b.ess[b] = ess;
       a.b.tess[b] = tess;
       a.b.perplexity[b] = perp;
@@ -142,49 +178,31 @@ __global__ void __launch_bounds__(256) cs_lair_resample_kernel(const CsResampleA
   }
 
   // ---- resampling within groups ----
-  const int g_s = kp_s % G, cc_s = kp_s / G;
-  const int li_s = i_s * c + cc_s;  // position inside the group, '(i c)' order
-  // group log-normaliser
-  float lse_g = 0.0f;
-  for (int g = 0; g < G; ++g) {
-    const float v = wave_logsumexp(tlw, act && g_s == g);
-    if (g_s == g) lse_g = v;
-  }
-  const float nl = tlw - lse_g;  // normalised log-weight (Categorical.logits)
+  const float nl = tlw - seg_lse(tlw, true);  // normalised log-weight (Categorical.logits)
   if (act) a.b.norm_log_w[b * S + (int64_t)g_s * (I * c) + li_s] = nl;
-
   float p;
   if (a.cfg.method == CS_RM_MULTINOMIAL) {
     // Categorical.probs = softmax(normalised logits)
-    float mx = 0.0f, sm = 1.0f;
-    for (int g = 0; g < G; ++g) {
-      const bool in = act && g_s == g;
-      const float m = wave_max(in ? nl : -INFINITY);
-      const float su = wave_sum(in ? expf(nl - m) : 0.0f);
-      if (g_s == g) { mx = m; sm = su; }
-    }
-    p = act ? expf(nl - mx) / sm : 0.0f;
+    const float mx = seg_max(nl, true);
+    const float ex = expf(nl - mx);
+    p = ex / seg_sum(ex, true);
   } else {
     // systematic: exp(normalised log-weights), renormalised by their sum (:813-817)
-    float sm = 1.0f;
-    const float e = act ? expf(nl) : 0.0f;
-    for (int g = 0; g < G; ++g) {
-      const float su = wave_sum((act && g_s == g) ? e : 0.0f);
-      if (g_s == g) sm = su;
-    }
-    p = e / sm;
+    const float ex = expf(nl);
+    p = ex / seg_sum(ex, true);
   }
   // sequential float32 running sum inside each group, in member order
   float run = 0.0f, cum = 0.0f;
   for (int jj = 0; jj < S; ++jj) {
-    const float pj = __shfl(p, jj);
-    const int gj = (jj % Kp) % G;
-    if (gj == g_s) run += pj;
-    if (lane == jj) cum = run;
+    const float pj = __shfl(p, base + jj);
+    if ((jj % Kp) % G == g_s) run += pj;
+    if (s == jj) cum = run;
   }
-  const bool last_in_group = act && (i_s == I - 1) && (cc_s == c - 1);
+  const bool last_in_group = (i_s == I - 1) && (cc_s == c - 1);
+  const unsigned long long ex_mask = (S == 64 ? ~0ull : ((1ull << S) - 1ull)) << base;
 
   const int ndraw_sets = (a.b.latents_resampled != nullptr) ? 2 : 1;
+  int* my_idx = l_idx + e_l * 2 * Kp;
   for (int set = 0; set < ndraw_sets; ++set) {
     if (a.cfg.method == CS_RM_MULTINOMIAL) {
       // torch.multinomial: cum / total, last forced to 1, left bisection with float64 uniforms
@@ -193,26 +211,26 @@ __global__ void __launch_bounds__(256) cs_lair_resample_kernel(const CsResampleA
       const double* uin = set == 0 ? a.b.u_res : a.b.u_res2;
       for (int g = 0; g < G; ++g) {
         for (int t = 0; t < c; ++t) {
-          double u;
-          if (uin) u = valid ? uin[(b * G + g) * c + t] : 0.0;
-          else u = cs_uniform64_elem(a.rng, set == 0 ? CS_STREAM_URES : CS_STREAM_URES2, a.rng.row_offset + b,
-                                     (uint32_t)(g * c + t));
+          double u = 0.0;
+          if (act) {
+            if (uin) u = uin[(b * G + g) * c + t];
+            else u = cs_uniform64_elem(a.rng, set == 0 ? CS_STREAM_URES : CS_STREAM_URES2, a.rng.row_offset + b,
+                                       (uint32_t)(g * c + t));
+          }
           const unsigned long long mask = __ballot(act && g_s == g && (double)cn < u);
-          int li = __popcll(mask);
+          int li = __popcll(mask & ex_mask);
           if (li > I * c - 1) li = I * c - 1;
           const int il = li / c, cl = li - il * c;
-          if (lane == 0) l_idx[set * Kp + t * G + g] = il * Kp + cl * G + g;
+          if (act && s == 0) my_idx[set * Kp + t * G + g] = il * Kp + cl * G + g;
         }
       }
     } else {
       const float* uin = set == 0 ? a.b.u_sys : a.b.u_sys2;
       // n = clamp(floor(cumsum(p)*m + U), 0, m); index[t] = #{members : n <= t}
       float U = 0.0f;
-      for (int g = 0; g < G; ++g) {
-        float ug;
-        if (uin) ug = valid ? uin[b * G + g] : 0.0f;
-        else ug = cs_uniform_elem(a.rng, set == 0 ? CS_STREAM_URES : CS_STREAM_URES2, a.rng.row_offset + b, (uint32_t)g);
-        if (g_s == g) U = ug;
+      if (act) {
+        if (uin) U = uin[b * G + g_s];
+        else U = cs_uniform_elem(a.rng, set == 0 ? CS_STREAM_URES : CS_STREAM_URES2, a.rng.row_offset + b, (uint32_t)g_s);
       }
       float nf = floorf(cum * (float)c + U);
       nf = fminf(fmaxf(nf, 0.0f), (float)c);
@@ -220,53 +238,74 @@ __global__ void __launch_bounds__(256) cs_lair_resample_kernel(const CsResampleA
       for (int g = 0; g < G; ++g) {
         for (int t = 0; t < c; ++t) {
           const unsigned long long mask = __ballot(act && g_s == g && n <= t);
-          int li = __popcll(mask);
+          int li = __popcll(mask & ex_mask);
           if (li > I * c - 1) li = I * c - 1;  // the reference would index out of bounds here
           const int il = li / c, cl = li - il * c;
-          if (lane == 0) l_idx[set * Kp + t * G + g] = il * Kp + cl * G + g;
+          if (act && s == 0) my_idx[set * Kp + t * G + g] = il * Kp + cl * G + g;
         }
       }
     }
   }
   __syncthreads();
-  if (valid && lane < Kp) {
-    a.b.idx[b * Kp + lane] = l_idx[lane];
-    if (ndraw_sets == 2 && a.b.idx2) a.b.idx2[b * Kp + lane] = l_idx[Kp + lane];
+  for (int t = lane; t < ne * Kp; t += 64) {
+    const int e = t / Kp, n = t - e * Kp;
+    a.b.idx[(b0 + e) * Kp + n] = l_idx[e * 2 * Kp + n];
+    if (ndraw_sets == 2 && a.b.idx2) a.b.idx2[(b0 + e) * Kp + n] = l_idx[e * 2 * Kp + Kp + n];
   }
-  if (!valid) return;
 
   // ---- resampled latents (second, independent draw; vae_imputation.py:649-650) ----
   if (ndraw_sets == 2) {
-    for (int t = lane; t < Kp * Zd; t += 64) {
-      const int n = t / Zd, d = t - n * Zd;
-      a.b.latents_resampled[b * Kp * Zd + t] = l_z[l_idx[Kp + n] * (Zd + 1) + d];
+    for (int t = lane; t < ne * Kp * Zd; t += 64) {
+      const int en = t / Zd, d = t - en * Zd;
+      const int e = en / Kp, n = en - e * Kp;
+      a.b.latents_resampled[b0 * Kp * Zd + t] = l_z[(e * S + l_idx[e * 2 * Kp + Kp + n]) * (Zd + 1) + d];
     }
   }
 
   // ---- sample the missing values from the resampled generator parameters and impute ----
-  const uint8_t* mr = a.b.M + b * D;
-  for (int n = 0; n < K; ++n) {
-    const int src = l_idx[n];
+  // work item = 4 consecutive dimensions of one chain (one Philox block = 4 normals)
+  const int DQ = (D + 3) >> 2;
+  const bool bern = a.cfg.gen_dist == CS_DIST_BERN;
+  const bool clip = a.b.clip_min || a.b.clip_max;
+  for (int t = lane; t < ne * K * DQ; t += 64) {
+    const int en = t / DQ, dq = t - en * DQ;
+    const int e = en / K, n = en - e * K;
+    const int64_t be = b0 + e;
+    const int src = l_idx[e * 2 * Kp + n];
     const int i = src / Kp, kp = src - i * Kp;
-    const int64_t rho = ((int64_t)i * B + b) * Kp + kp;
-    float* xr = a.b.X + (b * K + n) * D;
-    const int64_t xrow = (a.rng.row_offset + b) * K + n;
-    for (int d = lane; d < D; d += 64) {
-      float xm;
-      if (a.cfg.gen_dist == CS_DIST_BERN) {
-        const float u = a.b.eps_x ? a.b.eps_x[(b * K + n) * D + d] : cs_uniform_elem(a.rng, CS_STREAM_X, xrow, d);
-        xm = (u < cs_sigmoid(a.b.gen[rho * D + d])) ? 1.0f : 0.0f;
+    const int64_t rho = ((int64_t)i * B + be) * Kp + kp;
+    float* xr = a.b.X + (be * K + n) * D;
+    const uint8_t* mr = a.b.M + be * D;
+    float dr[4];
+    if (a.b.eps_x) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dr[r] = (4 * dq + r < D) ? a.b.eps_x[(be * K + n) * D + 4 * dq + r] : 0.0f;
+    } else {
+      uint32_t x[4];
+      cs_philox_block(a.rng, CS_STREAM_X, (a.rng.row_offset + be) * K + n, (uint32_t)dq, x);
+      if (bern) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dr[r] = cs_u01f(x[r]);
       } else {
-        const float e = a.b.eps_x ? a.b.eps_x[(b * K + n) * D + d] : cs_normal_elem(a.rng, CS_STREAM_X, xrow, d);
-        xm = a.b.gen[rho * 2 * D + d] + a.b.gen[rho * 2 * D + D + d] * e;
+        const f32x4 nn = cs_normal4(x);
+        dr[0] = nn.x; dr[1] = nn.y; dr[2] = nn.z; dr[3] = nn.w;
       }
-      const float xo = xr[d];
-      const float m = (float)mr[d];
-      float xn = xo * m + xm * (1.0f - m);
-      if (a.b.clip_min) xn = (xn != xn) ? xn : fmaxf(xn, a.b.clip_min[d]);
-      if (a.b.clip_max) xn = (xn != xn) ? xn : fminf(xn, a.b.clip_max[d]);
-      if ((a.b.clip_min || a.b.clip_max) && !(fabsf(xn) < INFINITY)) xn = xo;
-      xr[d] = xn;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int d = 4 * dq + r;
+      if (d < D) {
+        float xm;
+        if (bern) xm = (dr[r] < cs_sigmoid(a.b.gen[rho * D + d])) ? 1.0f : 0.0f;
+        else xm = a.b.gen[rho * 2 * D + d] + a.b.gen[rho * 2 * D + D + d] * dr[r];
+        const float xo = xr[d];
+        const float m = (float)mr[d];
+        float xn = xo * m + xm * (1.0f - m);
+        if (a.b.clip_min) xn = (xn != xn) ? xn : fmaxf(xn, a.b.clip_min[d]);
+        if (a.b.clip_max) xn = (xn != xn) ? xn : fminf(xn, a.b.clip_max[d]);
+        if (clip && !(fabsf(xn) < INFINITY)) xn = xo;
+        xr[d] = xn;
+      }
     }
   }
 }
@@ -358,14 +397,15 @@ extern "C" int cs_lair_resample_impute(const cs_lair_cfg* c, const cs_lair_bufs*
   }
   CS_REQUIRE(c->method == CS_RM_MULTINOMIAL || c->method == CS_RM_SYSTEMATIC, "bad resampling method");
   if (c->B == 0) return CS_OK;
-  a.lds_per_wave = 3 * a.Kp * c->Zd + a.S * (c->Zd + 1) + 2 * a.Kp;
-  a.lds_per_wave = (a.lds_per_wave + 3) & ~3;
-  int waves = 4;
-  while (waves > 1 && (size_t)waves * a.lds_per_wave * 4 > 60 * 1024) waves >>= 1;
-  CS_REQUIRE((size_t)waves * a.lds_per_wave * 4 <= 64 * 1024, "proposal set too large for the LDS working set");
-  const unsigned grid = (unsigned)((c->B + waves - 1) / waves);
-  hipLaunchKernelGGL(cs_lair_resample_kernel, dim3(grid), dim3(64 * waves), (size_t)waves * a.lds_per_wave * 4,
-                     (hipStream_t)stream, a);
+  const int per_example = 3 * a.Kp * c->Zd + a.S * (c->Zd + 1) + 2 * a.Kp;  // floats of LDS
+  a.E = 64 / a.S;
+  // more examples per wavefront fill more lanes, but the LDS working set limits how many
+  // wavefronts are resident; ~12 KB per wavefront measured best (MiniBooNE shape)
+  while (a.E > 1 && (size_t)a.E * per_example * 4 > 12 * 1024) --a.E;
+  CS_REQUIRE((size_t)a.E * per_example * 4 <= 64 * 1024, "proposal set too large for the LDS working set");
+  a.lds_per_wave = a.E * per_example;
+  const unsigned grid = (unsigned)((c->B + a.E - 1) / a.E);
+  hipLaunchKernelGGL(cs_lair_resample_kernel, dim3(grid), dim3(64), (size_t)a.lds_per_wave * 4, (hipStream_t)stream, a);
   CS_HIP(hipGetLastError());
   return CS_OK;
 }

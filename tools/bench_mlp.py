@@ -7,7 +7,6 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from oracle import cs_oracle as O  # noqa: E402
 from vae_conditional_sampling_amd import _lib  # noqa: E402
 from vae_conditional_sampling_amd.models import VAE, ResidualFCNetwork  # noqa: E402
 from vae_conditional_sampling_amd.sampling import engine  # noqa: E402
@@ -17,10 +16,8 @@ def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
     reps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
     D, Zd, H, K, R = 43, 32, 256, 4, 1
-    enc_w = O.make_resfc_weights(D, 2 * Zd, 5, H, 1)
-    dec_w = O.make_resfc_weights(Zd, 2 * D, 2, H, 2)
-    enc = ResidualFCNetwork(D, 2 * Zd, 5, H).load_weight_dict(enc_w)
-    dec = ResidualFCNetwork(Zd, 2 * D, 2, H).load_weight_dict(dec_w)
+    enc = ResidualFCNetwork(D, 2 * Zd, 5, H)
+    dec = ResidualFCNetwork(Zd, 2 * D, 2, H)
     model = VAE(dec, "normal_with_eps", enc, "normal_with_eps").cuda()
     X = torch.randn(B, K, D, device="cuda")
     M8 = (torch.rand(B, D, device="cuda") > 0.5).to(torch.uint8)
@@ -54,10 +51,8 @@ def trace(B=65536):
     """Per-wave time line of one encoder and one decoder launch (clock64 stamps)."""
     import numpy as np
     D, Zd, H, K, R = 43, 32, 256, 4, 1
-    enc_w = O.make_resfc_weights(D, 2 * Zd, 5, H, 1)
-    dec_w = O.make_resfc_weights(Zd, 2 * D, 2, H, 2)
-    enc = ResidualFCNetwork(D, 2 * Zd, 5, H).load_weight_dict(enc_w)
-    dec = ResidualFCNetwork(Zd, 2 * D, 2, H).load_weight_dict(dec_w)
+    enc = ResidualFCNetwork(D, 2 * Zd, 5, H)
+    dec = ResidualFCNetwork(Zd, 2 * D, 2, H)
     model = VAE(dec, "normal_with_eps", enc, "normal_with_eps").cuda()
     X = torch.randn(B, K, D, device="cuda")
     M8 = (torch.rand(B, D, device="cuda") > 0.5).to(torch.uint8)
@@ -69,18 +64,49 @@ def trace(B=65536):
     he, hd = model.var_latent_network.packed().handle, model.generator_network.packed().handle
     st = _lib.current_stream()
     rng = _lib.make_rng(1, 0, 0)
-    for name, fn, rows, npts in (("enc", lambda: L.cs_lair_encode(he, C.byref(cfg), C.byref(bufs), st), B * K, 9),
-                                 ("dec", lambda: L.cs_lair_decode(hd, C.byref(cfg), C.byref(bufs), C.byref(rng), st), B * (K + R), 6)):
+    for name, fn, rows, npts in (("enc", lambda: L.cs_lair_encode(he, C.byref(cfg), C.byref(bufs), st), B * K, 10),
+                                 ("dec", lambda: L.cs_lair_decode(hd, C.byref(cfg), C.byref(bufs), C.byref(rng), st), B * (K + R), 7)):
         fn(); torch.cuda.synchronize()
-        tiles = (rows + 31) // 32
+        tiles = (rows + 15) // 16
         buf = torch.zeros(tiles, 16, dtype=torch.int64, device="cuda")
         L.cs_debug_set_trace(buf.data_ptr())
-        fn(); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); fn(); e1.record(); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1)
         L.cs_debug_set_trace(None)
         t = buf.cpu().numpy()[:, :npts].astype(np.float64)
         d = np.diff(t, axis=1)
         print(name, "tiles", tiles, "segment medians (ticks):", np.median(d, axis=0).astype(int).tolist(),
-              "total median", int(np.median(t[:, -1] - t[:, 0])), "kernel span", int(t[:, -1].max() - t[:, 0].min()))
+              "total median", int(np.median(t[:, -1] - t[:, 0])))
+        # occupancy time line per XCD (the tick counters of different XCDs are not aligned)
+        raw = buf.cpu().numpy()
+        hw = raw[:, 15]
+        xcc = (hw >> 32) & 0xF
+        hwid = hw & 0xFFFFFFFF
+        cu = (hwid >> 8) & 0xF; sh = (hwid >> 12) & 0x1; se = (hwid >> 13) & 0x7; simd = (hwid >> 4) & 0x3
+        t0, t1 = raw[:, 0].astype(np.float64), raw[:, npts - 1].astype(np.float64)
+        print(name, f"launch {ms:.3f} ms = {ms * 2.39e6:.0f} ticks at 2.39 GHz")
+        # per CU (tick counters of different XCDs / shader engines are not aligned)
+        key = ((xcc * 8 + se) * 2 + sh) * 16 + cu
+        spans, busy = [], []
+        shown = 0
+        for k_ in sorted(set(key.tolist())):
+            sel = key == k_
+            base = t0[sel].min()
+            a0, a1 = t0[sel] - base, t1[sel] - base
+            spans.append(a1.max())
+            busy.append((a1 - a0).sum() / 8.0 / a1.max())
+            if shown < 2:
+                shown += 1
+                edges = np.linspace(0, a1.max(), 21)
+                occ = [int(((a0 <= e) & (a1 > e)).sum()) for e in edges[:-1]]
+                print(f"  cu key {k_}: {sel.sum()} waves, span {a1.max():.0f} ticks, resident waves at 20 points: {occ}")
+                order = np.argsort(a0)
+                print("   starts:", (a0[order][::4] / 1e3).astype(int).tolist())
+                print("   ends:  ", (np.sort(a1)[::4] / 1e3).astype(int).tolist())
+        spans, busy = np.array(spans), np.array(busy)
+        print(f"  {len(spans)} CUs: span median {np.median(spans):.0f} min {spans.min():.0f} max {spans.max():.0f} ticks;",
+              f"mean residency {busy.mean() * 8:.2f} of 8 wave slots; launch/span tick rate {np.median(spans) / (ms * 1e6):.3f} GHz")
 
 
 if __name__ == "__main__":

@@ -1,5 +1,6 @@
 // Micro-benchmark: issue rate of v_mfma_f32_32x32x2_f32 under the operand patterns of the fused
 // MLP kernel.  One wave per SIMD (256 threads per block), `blocks` blocks.
+#include <cstring>
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -200,8 +201,34 @@ void run(int blocks, int iters) {
   hipFree(out); hipFree(ticks); hipFree(gsrc);
 }
 
+// Sustained clock: a pure MFMA stream on all CUs for about a second; prints the device tick rate
+// (ticks per wall ns) and the delivered rate of each ~35 ms launch.
+void sustain() {
+  const int blocks = 256, iters = 20000, reps = 30;
+  float* out; long long* ticks; float4* gsrc;
+  hipMalloc(&gsrc, 1024 * 256 * 16 + 4096); hipMemset(gsrc, 0, 1024 * 256 * 16);
+  hipMalloc(&out, blocks * 256 * 4); hipMalloc(&ticks, blocks * 4 * 8);
+  hipEvent_t e[reps + 1];
+  for (auto& x : e) hipEventCreate(&x);
+  hipEventRecord(e[0]);
+  for (int r = 0; r < reps; ++r) {
+    hipLaunchKernelGGL(k<4>, dim3(blocks), dim3(256), 0, 0, out, ticks + (size_t)0, iters, 1.0f, gsrc);
+    hipEventRecord(e[r + 1]);
+  }
+  hipDeviceSynchronize();
+  long long h[4]; hipMemcpy(h, ticks, 32, hipMemcpyDeviceToHost);
+  for (int r = 0; r < reps; ++r) {
+    float ms; hipEventElapsedTime(&ms, e[r], e[r + 1]);
+    const double n = 64.0 * iters;
+    printf("sustain rep %2d: %.3f ms, %.1f TFLOP/s%s\n", r, ms, blocks * 4 * n * 4096 / (ms * 1e-3) / 1e12,
+           r == reps - 1 ? "" : "");
+    if (r == reps - 1) printf("last launch: %.1f ticks/MFMA, tick rate %.3f GHz\n", h[0] / n, h[0] / (ms * 1e6));
+  }
+}
+
 int main(int argc, char** argv) {
   int iters = 2000;
+  if (argc > 1 && !strcmp(argv[1], "sustain")) { sustain(); return 0; }
   for (int blocks : {1, 256}) {
     run<0>(blocks, iters); run<1>(blocks, iters); run<2>(blocks, iters); run<3>(blocks, iters); run<4>(blocks, iters); run<5>(blocks, iters); run<6>(blocks, iters); run<7>(blocks, iters); run<8>(blocks, iters); run<9>(blocks, iters); run<10>(blocks, iters); run<11>(blocks, iters); run<12>(blocks, iters); run<13>(blocks, iters); run<14>(blocks, iters); run<15>(blocks, iters); run<16>(blocks, iters * 64 / 80);
   }

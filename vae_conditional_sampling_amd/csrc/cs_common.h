@@ -117,17 +117,36 @@ __device__ inline double cs_uniform64_elem(const CsPhilox& p, uint32_t stream, i
   return (e & 1u) ? cs_u01d(x[2], x[3]) : cs_u01d(x[0], x[1]);
 }
 
-// torch.nn.functional.softplus (beta 1, threshold 20).
-__device__ inline float cs_softplus(float x) { return x > 20.0f ? x : log1pf(expf(x)); }
-// torch.distributions.Normal.log_prob with the operation order of the reference's torch.
+// exp / log / reciprocal through the hardware transcendental instructions (v_exp_f32 = 2^x,
+// v_log_f32 = log2, v_rcp_f32; each accurate to 1 ulp).  The library versions cost 50-150
+// instructions apiece, which the epilogues of the fused kernels pay per output element; these
+// stay within a few ulp (the product x*log2(e) is formed in two parts so that large |x| does not
+// lose relative accuracy).
+__device__ inline float cs_expf(float x) {
+  const float t = x * 1.44269502162933349609375f;
+  const float r = __builtin_fmaf(x, 1.44269502162933349609375f, -t) + x * 1.92596299112661746e-8f;
+  const float e = __builtin_amdgcn_exp2f(t);
+  return __builtin_fmaf(e, r * 0.693147182464599609375f, e);
+}
+__device__ inline float cs_logf(float x) { return __builtin_amdgcn_logf(x) * 0.693147182464599609375f; }
+// log(1 + u) for u in [0, 1]: log(w) * u / (w - 1) with w = fl(1 + u) cancels the rounding of w.
+__device__ inline float cs_log1pf01(float u) {
+  const float w = 1.0f + u;
+  const float d = w - 1.0f;
+  return d == 0.0f ? u : cs_logf(w) * (u * __builtin_amdgcn_rcpf(d));
+}
+// torch.nn.functional.softplus (beta 1, threshold 20): log(1 + e^x) = max(x, 0) + log1p(e^-|x|);
+// above the threshold the correction is below half an ulp of x, so x itself comes out.
+__device__ inline float cs_softplus(float x) { return fmaxf(x, 0.0f) + cs_log1pf01(cs_expf(-fabsf(x))); }
+// torch.distributions.Normal.log_prob: -(x-loc)^2 / (2 scale^2) - log(scale) - log(sqrt(2 pi)).
 __device__ inline float cs_normal_logpdf(float x, float loc, float scale) {
   float d = x - loc;
-  return -(d * d) / (2.0f * (scale * scale)) - logf(scale) - CS_LOG_SQRT_2PI;
+  return -(d * d) * __builtin_amdgcn_rcpf(2.0f * (scale * scale)) - cs_logf(scale) - CS_LOG_SQRT_2PI;
 }
 __device__ inline float cs_stdnormal_logpdf(float z) { return -(z * z) / 2.0f - CS_LOG_SQRT_2PI; }
 // -BCEWithLogits(l, x) = x*l - softplus(l), in torch's stable form.
 __device__ inline float cs_bernoulli_logpmf(float x, float l) {
-  return -((1.0f - x) * l + fmaxf(-l, 0.0f) + log1pf(expf(-fabsf(l))));
+  return -((1.0f - x) * l + fmaxf(-l, 0.0f) + cs_log1pf01(cs_expf(-fabsf(l))));
 }
-__device__ inline float cs_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ inline float cs_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + cs_expf(-x)); }
 #endif

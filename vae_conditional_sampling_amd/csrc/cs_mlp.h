@@ -10,8 +10,8 @@ struct CsMlpDev {
   int nkt0;              // first-layer k-tiles = ceil(in_dim/32)
   int in_dim, out_dim;
   int out_half;          // out_dim / out_split
-  int tph;               // output tiles per half = ceil(out_half/32)
-  int nt;                // hidden/32
+  int tph;               // 16-feature output tiles per half = ceil(out_half/16)
+  int nt;                // hidden/16
   int nto;               // output tiles = out_split*tph
   int split;
   int bias_stride;

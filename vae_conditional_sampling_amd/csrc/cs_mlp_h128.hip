@@ -1,0 +1,4 @@
+// Fused residual-MLP kernel instances for hidden width 128 (see cs_mlp_kernel.inc).
+#include "cs_mlp_kernel.inc"
+
+int cs_mlp_launch_h128(const CsMlpArgs& a, hipStream_t stream) { return cs_mlp_launch_nt<8>(a, stream); }

@@ -1,0 +1,4 @@
+// Fused residual-MLP kernel instances for hidden width 64 (see cs_mlp_kernel.inc).
+#include "cs_mlp_kernel.inc"
+
+int cs_mlp_launch_h64(const CsMlpArgs& a, hipStream_t stream) { return cs_mlp_launch_nt<4>(a, stream); }

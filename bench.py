@@ -62,7 +62,6 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
 
-    from oracle import cs_oracle as O
     from vae_conditional_sampling_amd import _lib
     from vae_conditional_sampling_amd.models import VAE, ResidualFCNetwork
     from vae_conditional_sampling_amd.sampling import engine
@@ -71,10 +70,16 @@ def main():
     D, Zd, H, K, R = w["D"], w["Zd"], w["H"], w["K"], w["R"]
     B = args.batch
     seed = 20220118
-    enc_w = O.make_resfc_weights(D, 2 * Zd, w["nbe"], H, seed)
-    dec_w = O.make_resfc_weights(Zd, 2 * D, w["nbd"], H, seed + 1)
-    enc = ResidualFCNetwork(D, 2 * Zd, w["nbe"], H).load_weight_dict(enc_w)
-    dec = ResidualFCNetwork(Zd, 2 * D, w["nbd"], H).load_weight_dict(dec_w)
+    torch.manual_seed(seed)  # random-init weights of the named architecture (torch's nn.Linear default)
+    enc = ResidualFCNetwork(D, 2 * Zd, w["nbe"], H)
+    dec = ResidualFCNetwork(Zd, 2 * D, w["nbd"], H)
+    def cpu_copy(net):  # float32 CPU copies for the CPU baseline leg
+        d = net.weight_dict()
+        c = lambda t: t.detach().clone()
+        return {"W0": c(d["W0"]), "b0": c(d["b0"]), "blocks": [tuple(c(t) for t in b) for b in d["blocks"]],
+                "Wf": c(d["Wf"]), "bf": c(d["bf"])}
+
+    enc_w, dec_w = cpu_copy(enc), cpu_copy(dec)
     model = VAE(dec, "normal_with_eps", enc, "normal_with_eps").to(dev)
 
     # synthetic standardised data, 50 % uniform missingness, this rank's shard
@@ -153,6 +158,17 @@ def main():
     dec_tf = dec_flops / (dec_ms * 1e-3) / 1e12
     value = world * B * K * args.steps / elapsed
 
+    # HBM bytes per encoder launch from the PMC counters of a profiled run of this command
+    # (tools/pmc_summary.py writes the file; null when it has not been collected)
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_summary.json")) as f:
+            pmc = json.load(f)
+        if pmc.get("workload") == args.workload and pmc.get("examples_per_gpu") == B:
+            traffic = pmc["encoder_launch"]["hbm_bytes"]
+    except (OSError, KeyError, ValueError):
+        pass
+
     out = {
         "metric": "conditional samples/sec (N x K chains) for LAIR",
         "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -163,14 +179,15 @@ def main():
                    "examples_per_gpu": B, "chains_per_gpu": B * K, "sharding": f"examples x{world}, no collective in loop"},
         "roofline": {"bound": "mfma", "kernel": "cs_mlp_kernel (encoder launch)", "achieved": enc_tf,
                      "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": enc_tf / F32_MFMA_PEAK_TFLOPS,
-                     "traffic": None, "flops_per_launch": enc_flops, "avg_launch_ms": enc_ms},
+                     "traffic": traffic, "flops_per_launch": enc_flops, "avg_launch_ms": enc_ms},
         "kernels": {"encoder_ms": enc_ms, "decoder_ms": dec_ms, "resample_impute_ms": res_ms,
                     "decoder_tflops": dec_tf, "decoder_frac": dec_tf / F32_MFMA_PEAK_TFLOPS,
                     "step_flops": enc_flops + dec_flops,
                     "step_mfma_frac": (enc_flops + dec_flops) / ((enc_ms + dec_ms + res_ms) * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS},
     }
 
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:
+        from oracle import cs_oracle as O  # the checker, used here only as the timed CPU baseline
         # CPU baseline: the torch-CPU oracle of this repository ("port") on a bounded sample of
         # the same workload: the reference configuration's batch of 512 examples, timed for ~10 s.
         nthreads = min(torch.get_num_threads(), 16)

@@ -238,7 +238,8 @@ int cs_rng_uniform(const cs_rng* rng, uint32_t stream_id, int64_t rows, int32_t 
 int cs_rng_uniform64(const cs_rng* rng, uint32_t stream_id, int64_t rows, int32_t cols, double* out, void* stream);
 
 /* Profiling hook (no counterpart in the reference): when buf != NULL every fused-MLP launch
- * writes 16 clock stamps per 32-row tile into buf (device memory, 16*ceil(rows/32) int64). */
+ * writes 16 int64 per 16-row tile into buf (device memory, 16*ceil(rows/16) int64): clock stamps in
+ * slots 0..14, (XCC_ID << 32 | HW_ID) of the wavefront in slot 15. */
 int cs_debug_set_trace(long long* buf);
 
 #ifdef __cplusplus

@@ -20,9 +20,10 @@ int cs_mlp_launch_h128(const CsMlpArgs& a, hipStream_t stream);
 int cs_mlp_launch_h256(const CsMlpArgs& a, hipStream_t stream);
 
 static long long* g_trace = nullptr;
-// Profiling hook: when set, every fused-MLP launch writes 16 clock64() stamps per wavefront
-// (row tile) into buf: start, after prologue, after the first layer, after each block, after
-// the output layer, end.  buf must hold 16 * ceil(rows/32) entries.  NULL disables it.
+// Profiling hook: when set, every fused-MLP launch writes 16 int64 per wavefront (16-row tile)
+// into buf: clock64() stamps at start, after prologue, after the first layer, after each block,
+// after the output layer, end (slots 0..14) and where the wave ran (slot 15).  buf must hold
+// 16 * ceil(rows/16) entries.  NULL disables it.
 extern "C" int cs_debug_set_trace(long long* buf) {
   g_trace = buf;
   return CS_OK;

@@ -74,6 +74,36 @@ int cs_mlp_destroy(cs_mlp_t* net);
  * (neural_nets.py:163-169), i.e. model.var_latent_network(X) / model.generator_network(Z). */
 int cs_mlp_forward(const cs_mlp_t* net, const float* x, int64_t rows, float* y, void* stream);
 
+/* ---------------------------------------------------------------------------------------
+ * Layer-program networks: the convolutional ResNet encoder / decoder
+ * (ResNetEncoder.forward irwg/models/vae_resnet.py:128-149, EncoderBlock :60-78,
+ * ResNetDecoder.forward :259-277, DecoderBlock :166-184, Interpolate :14-22) and MLPs wider
+ * than the fused kernel covers (toy configuration, hidden 512).  The caller describes the
+ * network as a list of layers over numbered activation buffers; BatchNorm (eval mode) is
+ * folded into the convolution weights and a bias by the caller, Dropout is the identity.
+ * Activations are NHWC ([row, y, x, channel]); weights are given in torch's layouts
+ * (convolution [cout][cin][kh][kw], linear [out][in]) and repacked by the library.
+ * The handle is a cs_mlp_t: every entry point that takes an encoder / decoder accepts it.
+ */
+enum { CS_OP_CONV = 1, CS_OP_LINEAR = 2, CS_OP_AVGPOOL = 3, CS_OP_RESIZE = 4 };
+/* buffer ids: 0 = network input [rows,in_dim], 1..4 = scratch, 5 = network output [rows,out_dim] */
+enum { CS_NET_NBUF = 6, CS_NET_BUF_IN = 0, CS_NET_BUF_OUT = 5 };
+typedef struct {
+  int32_t op;             /* CS_OP_* */
+  int32_t src, dst, res;  /* buffer ids; res = -1: no residual input (added before the ReLU) */
+  int32_t relu;           /* 1: ReLU on the result */
+  int32_t cin, cout;      /* channels (LINEAR: in / out features; AVGPOOL, RESIZE: cin == cout) */
+  int32_t hin, win, hout, wout; /* spatial sizes of src and dst (LINEAR: all 1) */
+  int32_t ksize, stride, pad;   /* CONV: square kernel 1 or 3 */
+  int32_t upsample;       /* CONV: nearest-neighbour factor (1 or 2) applied to src first
+                             (Interpolate(scale_factor=2) + conv, vae_resnet.py:32-43) */
+  int32_t in_nchw, out_nchw; /* 1: src / dst is channel-major [row, channel, y, x] (image-shaped
+                             network inputs and outputs, flattened as the reference's view does) */
+  int64_t w_off, b_off;   /* offsets in floats into the weight blob; b_off = -1: no bias */
+} cs_layer_desc;
+int cs_net_create(const cs_layer_desc* layers, int32_t n_layers, const float* blob, int64_t blob_floats,
+                  int32_t in_dim, int32_t out_dim, int32_t out_split, cs_mlp_t** out);
+
 /* counter-RNG key */
 typedef struct {
   uint64_t seed;

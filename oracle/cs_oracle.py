@@ -68,10 +68,22 @@ def make_resfc_weights(in_dim, out_dim, num_blocks, hidden, seed):
     return {"W0": W0, "b0": b0, "blocks": blocks, "Wf": Wf, "bf": bf}
 
 
+def net_input_dim(w):
+    """Input width of a network weight dict (residual MLP or ResNet decoder)."""
+    cfg = w.get("cfg")
+    if isinstance(cfg, dict) and cfg.get("kind") == "resnet_dec":
+        return cfg["latent_dim"]
+    return w["W0"].shape[1]
+
+
 def resfc_forward(w, x):
     """h = relu(W0 x + b0); per block h = relu(h + W2 relu(W1 h + b1) + b2); y = Wf h + bf.
     (neural_nets.py:163-169 with :87-103; dropout is identity in eval mode; no norm layers
     in the configurations on the path.)"""
+    cfg = w.get("cfg") if isinstance(w, dict) else None
+    if isinstance(cfg, dict) and str(cfg.get("kind", "")).startswith("resnet"):
+        from . import cs_oracle_conv  # weight dicts of the convolutional nets carry their own forward
+        return cs_oracle_conv.net_forward(w, x)
     h = F.relu(F.linear(x, w["W0"], w["b0"]))
     for (W1, b1, W2, b2) in w["blocks"]:
         t = F.relu(F.linear(h, W1, b1))
@@ -109,6 +121,7 @@ def std_normal_log_prob(z):
 
 def bernoulli_log_prob(x, logits):
     """torch.distributions.Bernoulli(logits).log_prob = -BCEWithLogits(logits, x)."""
+    logits, x = torch.broadcast_tensors(logits, x)  # as torch.distributions.Bernoulli.log_prob does
     return -F.binary_cross_entropy_with_logits(logits, x, reduction="none")
 
 

@@ -109,7 +109,7 @@ class SeededSource:
 
 def initial_imputation(dec, X, M, src, gen_dist="normal_with_eps"):
     B, K, D = X.shape
-    Zd = dec["W0"].shape[1]
+    Zd = O.net_input_dim(dec)
     draws = {"z": src.normal(B * K, Zd),
              "eps_x": src.uniform(B * K, D) if gen_dist == "bern" else src.normal(B * K, D)}
     return O.vae_samples_imputation(dec, X, M, draws, gen_dist=gen_dist)
@@ -140,7 +140,7 @@ def lair_sampler(enc, dec, X, M, src, *, num_iterations, num_imp_samples=1, weig
     """Generator over LAIR iterations; yields the dict the reference yields plus, when
     ``collect_proposals``, 'Z_prop' and 'log_weights' for the final resampling."""
     B, K, D = X.shape
-    Zd = dec["W0"].shape[1]
+    Zd = O.net_input_dim(dec)
     if clip_imputations:
         Xt = X[:, 0].clone() * M.squeeze(1)
         clip_max = torch.max(Xt, dim=0)[0] * 2
@@ -209,7 +209,7 @@ def acmwg_sampler(enc, dec, X, M, src, *, num_pseudo_warmup_iterations, num_mwg_
     {'X','Z' (absent during the irwg warm-up),'acceptance'} like the reference; MWG steps also
     carry 'accepted', 'log_accept' and 'slots' for the parity tests."""
     B, K, D = X.shape
-    Zd = dec["W0"].shape[1]
+    Zd = O.net_input_dim(dec)
     W = num_pseudo_warmup_iterations
     if warmup_method == "irwg":
         max_it = W * num_k_per_cluster + num_mwg_iterations

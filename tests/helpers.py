@@ -58,3 +58,33 @@ def seeded_inputs(B, K, D, seed, miss=0.5):
     X = X_true.unsqueeze(1).repeat(1, K, 1)
     X = X * M.unsqueeze(1) + torch.randn(B, K, D, generator=g) * (~M.unsqueeze(1))
     return X.contiguous(), M.unsqueeze(1).contiguous()
+
+
+# ResNet shapes of the conv fixtures (same table as oracle/check_conv_against_reference.py, which
+# generated tests/golden/conv_*.npz; weights are regenerated from the seed by the oracle)
+CONV_NETS = {
+    "gmm_like": dict(enc=dict(input_shape=(1, 14, 14), layers=[2, 2, 2, 2], layer_widths=[32, 64, 128, 128], latent_dim=2 * 8),
+                     dec=dict(output_shape=(2, 14, 14), layers=[2, 2, 2, 2], layer_upscale=[4, 7, None, None],
+                              layer_widths=[64, 32, 32, 32], downscaled_resolution=(1, 1), latent_dim=8, upscale_factor=4)),
+    "omni_like": dict(enc=dict(input_shape=(1, 28, 28), layers=[1, 1, 1, 1], layer_widths=[32, 32, 64, 64], latent_dim=2 * 10),
+                      dec=dict(output_shape=(1, 28, 28), layers=[1, 1, 1, 1], layer_upscale=[7, None, None, None],
+                               layer_widths=[64, 32, 32, 32], downscaled_resolution=(4, 4), latent_dim=10, upscale_factor=7)),
+}
+
+
+def conv_weights(net, seed):
+    from oracle import cs_oracle_conv as OC
+    n = CONV_NETS[net]
+    return (OC.make_resnet_encoder_weights(seed=seed, **n["enc"]), OC.make_resnet_decoder_weights(seed=seed + 1, **n["dec"]))
+
+
+def make_conv_model(net, enc_w, dec_w, latent_dist, gen_dist, device="cuda"):
+    """Product-side VAE with ResNet encoder / decoder loaded (strict) from the oracle's state dicts."""
+    from oracle import cs_oracle_conv as OC
+    from vae_conditional_sampling_amd.models import VAE
+    from vae_conditional_sampling_amd.models.vae_resnet import ResNetDecoder, ResNetEncoder
+    n = CONV_NETS[net]
+    enc, dec = ResNetEncoder(**n["enc"]), ResNetDecoder(**n["dec"])
+    enc.load_state_dict(OC.state_dict_of(enc_w), strict=True)
+    dec.load_state_dict(OC.state_dict_of(dec_w), strict=True)
+    return VAE(dec, gen_dist, enc, latent_dist).to(device)

@@ -1,0 +1,114 @@
+"""GPU parity tests of the convolutional ResNet path (layer programs through the C ABI) against
+the golden vectors recorded from the reference and the CPU oracle.
+
+The conv nets are ~20 layers deep with BatchNorm folded into the weights and a different summation
+order from torch's CPU convolutions, so raw network outputs are compared at CONV_RTOL; quantities
+of the sampling path keep the 1e-5 bar where they hold it (indices bit-exact).
+"""
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import CONV_NETS, assert_close, conv_weights, load_golden, make_conv_model, rel_err
+
+pytestmark = pytest.mark.gpu
+
+CONV_RTOL = 2e-5
+
+
+@pytest.mark.parametrize("net", ["gmm_like", "omni_like"])
+def test_resnet_forward_matches_reference_golden(net):
+    fx = load_golden(f"conv_forward_{net}")
+    enc_w, dec_w = conv_weights(net, int(fx["seed"]))
+    model = make_conv_model(net, enc_w, dec_w, "normal", "normal" if net == "gmm_like" else "bern")
+    x, z = torch.from_numpy(fx["x"]).cuda(), torch.from_numpy(fx["z"]).cuda()
+    y = model.var_latent_network(x)
+    assert y.shape == fx["enc_out"].shape
+    assert_close(y, fx["enc_out"], "encoder output", CONV_RTOL)
+    g = model.generator_network(z)
+    assert g.shape == fx["dec_out"].shape
+    assert_close(g, fx["dec_out"], "decoder output", CONV_RTOL)
+
+
+def test_resnet_forward_many_rows_matches_oracle():
+    """More rows than one 128-pixel tile boundary pattern, odd row count."""
+    from oracle import cs_oracle_conv as OC
+    enc_w, dec_w = conv_weights("gmm_like", 77)
+    model = make_conv_model("gmm_like", enc_w, dec_w, "normal", "normal")
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(37, 196, generator=g)
+    z = torch.randn(37, 8, generator=g)
+    with torch.no_grad():
+        assert_close(model.var_latent_network(x.cuda()), OC.resnet_encoder_forward(enc_w, x), "encoder", CONV_RTOL)
+        assert_close(model.generator_network(z.cuda()), OC.resnet_decoder_forward(dec_w, z), "decoder", CONV_RTOL)
+
+
+def test_wide_mlp_program_matches_oracle():
+    """Hidden width 512 (toy configuration) runs as a layer program of matrix-core GEMMs."""
+    from oracle import cs_oracle as O
+    from vae_conditional_sampling_amd.models import ResidualFCNetwork
+    for (i, o, nb, rows) in ((2, 2, 4, 14), (1, 4, 4, 70), (40, 64, 1, 300)):
+        w = O.make_resfc_weights(i, o, nb, 512, seed=11 + i)
+        net = ResidualFCNetwork(i, o, nb, 512).load_weight_dict(w).cuda().eval()
+        x = torch.randn(rows, i, generator=torch.Generator().manual_seed(3))
+        assert_close(net(x.cuda()), O.resfc_forward(w, x), "wide mlp forward")
+
+
+def test_lair_iteration_conv_matches_reference_golden():
+    from vae_conditional_sampling_amd.sampling.vae_imputation import importance_resampling_gibbs_iteration
+    fx = load_golden("conv_lair_gmm_like")
+    B, K, R, I, D, Zd, iters, seed = [int(v) for v in fx["cfg"]]
+    net = str(fx["net"])
+    enc_w, dec_w = conv_weights(net, seed)
+    model = make_conv_model(net, enc_w, dec_w, "normal_with_eps", "normal_with_eps")
+    X = torch.from_numpy(fx["X0"]).cuda()
+    M = torch.from_numpy(fx["M"]).cuda()
+    for t in range(iters):
+        draws = {"eps_z": torch.from_numpy(fx[f"t{t}_eps_z"]), "u_res": torch.from_numpy(fx[f"t{t}_u_res"]),
+                 "eps_x": torch.from_numpy(fx[f"t{t}_eps_x"])}
+        out = importance_resampling_gibbs_iteration(model, X, M, I, glr_cluster_size=None, weighting="dmis",
+                                                    resampling_method="multinomial", resampling_scheme="gr",
+                                                    num_prior_replenish_proposals=R, draws=draws)
+        ws = model._cs_workspaces[("lair", B, K, R, I, str(X.device))]
+        assert_close(ws.q[:, :, 0], fx[f"t{t}_q_loc"], "q loc", CONV_RTOL)
+        assert_close(ws.q[:, :, 1], fx[f"t{t}_q_scale"], "q scale", CONV_RTOL)
+        assert_close(out[6], fx[f"t{t}_Z_imp"], "Z_imp", CONV_RTOL)
+        assert_close(out[7], fx[f"t{t}_log_weights"], "log_weights", CONV_RTOL)
+        assert np.array_equal(ws.idx.cpu().numpy(), fx[f"t{t}_idx"]), "resampling indices differ"
+        assert_close(out[0], fx[f"t{t}_X_new"], "X_new", CONV_RTOL)
+        X = torch.from_numpy(fx[f"t{t}_X_new"]).cuda()  # continue from the reference's state
+
+
+def test_acmwg_sampler_conv_bernoulli_matches_reference_golden():
+    """Omniglot-like AC-MWG (ResNet nets, Bernoulli likelihood, irwg warm-up): the recorded draw tape
+    of the reference's sampler class is replayed into the HIP engine.  Binary imputations, accept
+    decisions and history slots are compared bit for bit."""
+    from tests.test_gpu_samplers import BASE_KW, tape_source
+    from vae_conditional_sampling_amd.sampling.test_step_vae_sampling import \
+        TestVAEAdaptiveCollapsedMetropolisWithinGibbs as Sampler
+    fx = load_golden("conv_acmwg_omni_like")
+    B, K, D, Zd, W, T, nkpc, cluster, R, seed = [int(v) for v in fx["cfg"]]
+    net = str(fx["net"])
+    enc_w, dec_w = conv_weights(net, seed)
+    model = make_conv_model(net, enc_w, dec_w, "normal", "bern")
+    s = Sampler(num_pseudo_warmup_iterations=W, num_mwg_iterations=T, prior_mixture_probability=float(fx["p"]),
+                warmup_method="irwg", num_copies=K, num_k_per_cluster=nkpc, glr_cluster_size=cluster,
+                num_prior_replenish_proposals=R, **BASE_KW)
+    s.set_model(model)
+    s.on_test_start()
+    s.draw_source = tape_source(fx)
+    X = torch.from_numpy(fx["X0"]).cuda()
+    M = torch.from_numpy(fx["M"]).cuda()
+    outs = []
+    for o in s.sampler(X, M):
+        outs.append({k: (v.clone() if torch.is_tensor(v) else v) for k, v in o.items()})
+    assert len(outs) == s.max_iterations == fx["X_seq"].shape[0]
+    assert s.draw_source.pos == len(s.draw_source.entries), "the engine did not consume the whole tape"
+    mwg = [o for o in outs if "_accepted" in o]
+    acc = np.stack([o["_accepted"].cpu().numpy().astype(bool) for o in mwg])
+    assert np.array_equal(acc, fx["accepted"]), "accept decisions differ"
+    slots = np.stack([o["_slots"].cpu().numpy() for o in mwg])
+    assert np.array_equal(slots, fx["slots"]), "history slots differ"
+    for t, o in enumerate(outs):
+        assert np.array_equal(o["X"].cpu().numpy(), fx["X_seq"][t].astype(np.float32)), f"binary imputations differ at {t}"
+    assert_close(outs[-1]["Z"], fx["Z_last"], "Z", CONV_RTOL)

@@ -32,6 +32,16 @@ class cs_mlp_desc(C.Structure):
                 ("hidden", C.c_int32), ("out_split", C.c_int32)]
 
 
+CS_OP_CONV, CS_OP_LINEAR, CS_OP_AVGPOOL, CS_OP_RESIZE = 1, 2, 3, 4
+CS_NET_BUF_IN, CS_NET_BUF_OUT = 0, 5
+
+
+class cs_layer_desc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("op", "src", "dst", "res", "relu", "cin", "cout", "hin", "win", "hout",
+                                         "wout", "ksize", "stride", "pad", "upsample", "in_nchw", "out_nchw")] + \
+               [("w_off", C.c_int64), ("b_off", C.c_int64)]
+
+
 class cs_rng(C.Structure):
     _fields_ = [("seed", C.c_uint64), ("iteration", C.c_uint32), ("example_offset", C.c_int64)]
 
@@ -94,6 +104,7 @@ def lib():
     vp, i64, u32, i32 = C.c_void_p, C.c_int64, C.c_uint32, C.c_int32
     L.cs_mlp_create.argtypes = [C.POINTER(cs_mlp_desc), vp, vp, vp, vp, vp, vp, C.POINTER(vp)]
     L.cs_mlp_destroy.argtypes = [vp]
+    L.cs_net_create.argtypes = [C.POINTER(cs_layer_desc), i32, vp, i64, i32, i32, i32, C.POINTER(vp)]
     L.cs_mlp_forward.argtypes = [vp, vp, i64, vp, vp]
     L.cs_lair_encode.argtypes = [vp, C.POINTER(cs_lair_cfg), C.POINTER(cs_lair_bufs), vp]
     L.cs_lair_decode.argtypes = [vp, C.POINTER(cs_lair_cfg), C.POINTER(cs_lair_bufs), C.POINTER(cs_rng), vp]
@@ -146,7 +157,95 @@ def make_bufs(**tensors):
     return b
 
 
-class PackedMLP:
+class _PackedBase:
+    handle = None
+    out_dim = 0
+
+    def forward(self, x):
+        shape = x.shape
+        x2 = x.reshape(-1, self.in_dim).contiguous().float()
+        y = torch.empty(x2.shape[0], self.out_dim, device=x.device, dtype=torch.float32)
+        check(lib().cs_mlp_forward(self.handle, ptr(x2), x2.shape[0], ptr(y), current_stream()))
+        return y.reshape(*shape[:-1], self.out_dim) if shape[-1] == self.in_dim else y
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None) is not None and _lib is not None:
+                _lib.cs_mlp_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+class ProgramBuilder:
+    """Accumulates the layer list and the weight blob of a layer-program network (cs_net_create).
+
+    Buffer ids: 0 = network input, 1..4 scratch, 5 = network output.  Weights are appended in
+    torch's layouts; every tensor starts at a multiple of 4 floats.
+    """
+
+    def __init__(self, in_dim, out_dim, out_split):
+        self.in_dim, self.out_dim, self.out_split = int(in_dim), int(out_dim), int(out_split)
+        self.layers, self.chunks, self.n = [], [], 0
+
+    def _add(self, t):
+        if t is None:
+            return -1
+        t = t.detach().to("cpu", torch.float32).contiguous().reshape(-1)
+        off = self.n
+        pad = (-t.numel()) % 4
+        self.chunks.append(t)
+        if pad:
+            self.chunks.append(torch.zeros(pad))
+        self.n += t.numel() + pad
+        return off
+
+    def conv(self, src, dst, weight, bias, *, hin, win, stride=1, upsample=1, relu=False, res=-1, in_nchw=False,
+             out_nchw=False):
+        cout, cin, k, _ = weight.shape
+        pad = (k - 1) // 2
+        hout = (hin * upsample + 2 * pad - k) // stride + 1
+        wout = (win * upsample + 2 * pad - k) // stride + 1
+        self.layers.append(cs_layer_desc(CS_OP_CONV, src, dst, res, int(relu), cin, cout, hin, win, hout, wout, k,
+                                         stride, pad, upsample, int(in_nchw), int(out_nchw), self._add(weight),
+                                         self._add(bias)))
+        return hout, wout
+
+    def linear(self, src, dst, weight, bias, *, relu=False, res=-1):
+        out, inp = weight.shape
+        self.layers.append(cs_layer_desc(CS_OP_LINEAR, src, dst, res, int(relu), inp, out, 1, 1, 1, 1, 1, 1, 0, 1, 0, 0,
+                                         self._add(weight), self._add(bias)))
+
+    def avgpool(self, src, dst, *, channels, hin, win):
+        self.layers.append(cs_layer_desc(CS_OP_AVGPOOL, src, dst, -1, 0, channels, channels, hin, win, 1, 1, 1, 1, 0, 1,
+                                         0, 0, 0, -1))
+
+    def resize(self, src, dst, *, channels, hin, win, hout, wout):
+        self.layers.append(cs_layer_desc(CS_OP_RESIZE, src, dst, -1, 0, channels, channels, hin, win, hout, wout, 1, 1,
+                                         0, 1, 0, 0, 0, -1))
+
+    def build(self):
+        return PackedProgram(self)
+
+
+class PackedProgram(_PackedBase):
+    """Device handle of a layer-program network (cs_net_create)."""
+
+    def __init__(self, b):
+        L = lib()
+        if not torch.cuda.is_available():
+            raise CsError("no GPU visible: libcsvae has no CPU path")
+        blob = torch.cat(b.chunks) if b.chunks else torch.zeros(4)
+        arr = (cs_layer_desc * len(b.layers))(*b.layers)
+        h = C.c_void_p()
+        check(L.cs_net_create(arr, len(b.layers), blob.data_ptr(), blob.numel(), b.in_dim, b.out_dim, b.out_split,
+                              C.byref(h)))
+        self.handle = h
+        self.in_dim, self.out_dim = b.in_dim, b.out_dim
+        self.num_layers = len(b.layers)
+
+
+class PackedMLP(_PackedBase):
     """Device handle of a residual MLP packed for the fused MFMA kernel (cs_mlp_create)."""
 
     def __init__(self, W0, b0, blocks, Wf, bf, out_split):
@@ -169,18 +268,3 @@ class PackedMLP:
         check(L.cs_mlp_create(C.byref(self.desc), W0.data_ptr(), b0.data_ptr(), Wb.data_ptr(), bb.data_ptr(),
                               Wf.data_ptr(), bf.data_ptr(), C.byref(h)))
         self.handle = h
-
-    def forward(self, x):
-        shape = x.shape
-        x2 = x.reshape(-1, shape[-1]).contiguous().float()
-        y = torch.empty(x2.shape[0], self.out_dim, device=x.device, dtype=torch.float32)
-        check(lib().cs_mlp_forward(self.handle, ptr(x2), x2.shape[0], ptr(y), current_stream()))
-        return y.reshape(*shape[:-1], self.out_dim)
-
-    def __del__(self):
-        try:
-            if getattr(self, "handle", None) is not None and _lib is not None:
-                _lib.cs_mlp_destroy(self.handle)
-                self.handle = None
-        except Exception:
-            pass

@@ -15,14 +15,17 @@ struct CsMlpDev {
   int nto;               // output tiles = out_split*tph
   int split;
   int bias_stride;
+  const void* prog;      // host pointer to a CsProgram when the network is a layer program, else null
 };
 
+struct CsProgram;
 struct cs_mlp {
   cs_mlp_desc desc;
   CsMlpDev dev;
   void* d_w;
   void* d_b;
   int device;
+  CsProgram* prog;  // layer-program networks (cs_net_create); null for the fused MLP
 };
 
 enum CsMlpMode : int { CS_MLP_RAW = 0, CS_MLP_ENC = 1, CS_MLP_DEC = 2 };

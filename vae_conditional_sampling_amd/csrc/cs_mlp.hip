@@ -10,6 +10,7 @@
 // the epilogue, and the proposal sampling Z = loc + scale*eps (vae_imputation.py:596-597)
 // fused into the decoder prologue.
 #include "cs_mlp.h"
+#include "cs_net.h"
 
 #include <cstdlib>
 #include <cstring>
@@ -33,6 +34,7 @@ int cs_mlp_launch(const CsMlpArgs& a_in, hipStream_t stream) {
   CsMlpArgs a = a_in;
   a.dbg = g_trace;
   if (a.rows <= 0) return CS_OK;
+  if (a.net.prog) return cs_prog_launch(a, stream);
   CS_REQUIRE(a.rows < ((int64_t)1 << 31) * 16, "too many rows");
   if (a.net.split == 2) CS_REQUIRE(a.net.nto == 2 * a.net.tph, "bad tile split");
   if (a.mode == CS_MLP_ENC) CS_REQUIRE(a.net.split == 2, "encoder output must be (loc | scale)");
@@ -117,6 +119,7 @@ extern "C" int cs_mlp_create(const cs_mlp_desc* d, const float* W0, const float*
   m->desc = *d;
   m->d_w = nullptr;
   m->d_b = nullptr;
+  m->prog = nullptr;
   hipError_t e = hipGetDevice(&m->device);
   if (e == hipSuccess) e = hipMalloc(&m->d_w, s.size() * sizeof(float));
   if (e == hipSuccess) e = hipMalloc(&m->d_b, bias.size() * sizeof(float));
@@ -140,14 +143,16 @@ extern "C" int cs_mlp_create(const cs_mlp_desc* d, const float* W0, const float*
   m->dev.nto = nto;
   m->dev.split = d->out_split;
   m->dev.bias_stride = bst;
+  m->dev.prog = nullptr;
   *out = m;
   return CS_OK;
 }
 
 extern "C" int cs_mlp_destroy(cs_mlp_t* m) {
   if (!m) return CS_OK;
-  (void)hipFree(m->d_w);
-  (void)hipFree(m->d_b);
+  cs_prog_destroy(m->prog);
+  if (m->d_w) (void)hipFree(m->d_w);
+  if (m->d_b) (void)hipFree(m->d_b);
   delete m;
   return CS_OK;
 }

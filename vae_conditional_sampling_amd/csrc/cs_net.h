@@ -1,0 +1,29 @@
+// Layer-program networks (convolutional ResNets, wide MLPs) -- internal interface.
+//
+// A network that does not fit the register-resident fused MLP kernel is a list of layers
+// executed one kernel per layer over NHWC activations in a per-handle workspace.
+#pragma once
+#include <vector>
+
+#include "cs_mlp.h"
+
+struct CsLayer {
+  cs_layer_desc d;
+  int64_t wp_off;  // offset (floats) of the MFMA-packed weights in the device blob, -1: direct kernel
+};
+
+struct CsProgram {
+  std::vector<CsLayer> layers;
+  float* d_blob = nullptr;   // caller's blob followed by the packed weights
+  int in_dim = 0, out_dim = 0;
+  int64_t buf_elems[CS_NET_NBUF] = {0};  // floats per network row of every buffer
+  // workspace (scratch buffers 1..4, staged input, raw output), grown on demand
+  float* ws = nullptr;
+  int64_t ws_rows = 0;
+  int device = 0;
+};
+
+// Runs the program in the role described by `a` (RAW / ENC / DEC, same meaning as for the
+// fused kernel).
+int cs_prog_launch(const CsMlpArgs& a, hipStream_t stream);
+void cs_prog_destroy(CsProgram* p);

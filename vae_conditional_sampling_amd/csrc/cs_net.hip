@@ -1,0 +1,527 @@
+// Layer-program networks: convolutional ResNet encoder / decoder and wide MLPs.
+//
+// Replaces ResNetEncoder.forward (irwg/models/vae_resnet.py:128-149; EncoderBlock :60-78),
+// ResNetDecoder.forward (:259-277; DecoderBlock :166-184; Interpolate :14-22) in eval mode
+// (BatchNorm folded by the caller, Dropout2d = identity), and ResidualFCNetwork.forward
+// (irwg/models/neural_nets.py:163-169) for widths the fused kernel does not cover.
+//
+// Execution model: one kernel per layer over NHWC activations held in a per-handle workspace;
+// rows (images) are processed in chunks so that the workspace stays within a fixed budget.
+//   * convolutions / linear layers with cin, cout multiples of 32: implicit GEMM on the exact-f32
+//     matrix cores (v_mfma_f32_32x32x2_f32), cs_conv_mfma_kernel;
+//   * everything else (first convolution from 1 channel, last convolution to 1-2 channels, the
+//     small linear layers): cs_conv_direct_kernel, one thread per output element;
+//   * the distribution parameterisation of VAE.create_distribution (irwg/models/vae.py:203-256),
+//     the masked log-likelihood (irwg/utils/weights.py:46-47) and Z = loc + scale*eps
+//     (vae_imputation.py:596-597) run as separate elementwise kernels around the layers, with the
+//     same buffer semantics as the prologue / epilogues of the fused MLP kernel.
+#include "cs_net.h"
+
+#include <cstring>
+
+namespace {
+
+// ----------------------------------------------------------------------------------------
+// implicit-GEMM convolution on the matrix cores
+// ----------------------------------------------------------------------------------------
+struct CsConvArgs {
+  const float* in;    // [n, hin, win, cin]
+  const float* w;     // packed [tap][cin/32][cout][32] (mfma) or torch [cout][cin][k][k] (direct)
+  const float* bias;  // [cout] or null
+  const float* res;   // [n, hout, wout, cout] or null
+  float* out;
+  int cin, cout, hin, win, hout, wout, ksize, stride, pad, us, relu, in_nchw, out_nchw;
+  int64_t npix;  // n * hout * wout
+};
+
+// Block = 4 wavefronts = 128 output pixels x (32*CT) output channels; a wavefront owns 32 pixels.
+// D[cout][pixel] = sum_k W[cout][k] * act[pixel][k]: the A operand is the weight tile, the B
+// operand the activation tile, so a lane ends up with 4 consecutive output channels of one pixel
+// per register quad (16-byte stores into NHWC).  K runs over (tap, 32-channel chunk); per chunk
+// both tiles sit in LDS as [row][32 k] (row stride 36 floats), and each lane reads 4 consecutive
+// k with one ds_read_b128: within a group of 8 k, MFMA step j uses k = 4*(lane>>5) + j on both
+// operands, which covers the 8 values once.  The next chunk is fetched into registers while the
+// current one is multiplied.
+template <int CT>
+__global__ void __launch_bounds__(256) cs_conv_mfma_kernel(const CsConvArgs a) {
+  constexpr int RS = 36;
+  __shared__ __attribute__((aligned(16))) float s_pix[128 * RS];
+  __shared__ __attribute__((aligned(16))) float s_w[CT * 32 * RS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = lane >> 5, l31 = lane & 31;
+  const int c4 = tid & 7;
+  const int ncc = a.cin >> 5;
+  const int nchunks = a.ksize * a.ksize * ncc;
+  const int hup = a.hin << a.us, wup = a.win << a.us;
+
+  // the 4 activation rows this thread stages
+  int ih0[4], iw0[4];
+  int64_t base[4];
+  bool pv[4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int64_t gp = (int64_t)blockIdx.x * 128 + (tid >> 3) + 32 * p;
+    pv[p] = gp < a.npix;
+    const int64_t g = pv[p] ? gp : 0;
+    const int hw = a.hout * a.wout;
+    const int64_t n = g / hw;
+    const int rem = (int)(g - n * hw);
+    const int oh = rem / a.wout, ow = rem - oh * a.wout;
+    ih0[p] = oh * a.stride - a.pad;
+    iw0[p] = ow * a.stride - a.pad;
+    base[p] = n * a.hin * a.win;
+  }
+  const float* wblk = a.w + (int64_t)blockIdx.y * (CT * 32) * 32;
+
+  f32x4 rp[4], rw[CT];
+  auto fetch = [&](int t) {
+    const int tap = t / ncc, cc = t - tap * ncc;
+    const int kh = tap / a.ksize, kw = tap - kh * a.ksize;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int uh = ih0[p] + kh, uw = iw0[p] + kw;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (pv[p] && uh >= 0 && uh < hup && uw >= 0 && uw < wup)
+        v = *(const f32x4*)(a.in + ((base[p] + (int64_t)(uh >> a.us) * a.win + (uw >> a.us)) * a.cin + cc * 32 + c4 * 4));
+      rp[p] = v;
+    }
+    const float* wt = wblk + (int64_t)t * a.cout * 32;
+#pragma unroll
+    for (int i = 0; i < CT; ++i) rw[i] = *(const f32x4*)(wt + (tid + 256 * i) * 4);
+  };
+  auto stash = [&]() {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) *(f32x4*)(s_pix + ((tid >> 3) + 32 * p) * RS + c4 * 4) = rp[p];
+#pragma unroll
+    for (int i = 0; i < CT; ++i) {
+      const int idx = tid + 256 * i;
+      *(f32x4*)(s_w + (idx >> 3) * RS + (idx & 7) * 4) = rw[i];
+    }
+  };
+
+  f32x16 acc[CT];
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[ct][r] = 0.0f;
+
+  fetch(0);
+  for (int t = 0; t < nchunks; ++t) {
+    __syncthreads();  // previous chunk's reads are done
+    stash();
+    __syncthreads();
+    if (t + 1 < nchunks) fetch(t + 1);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 b = *(const f32x4*)(s_pix + (wave * 32 + l31) * RS + 8 * g + 4 * h);
+      f32x4 w[CT];
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) w[ct] = *(const f32x4*)(s_w + (ct * 32 + l31) * RS + 8 * g + 4 * h);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[ct][j], b[j], acc[ct], 0, 0, 0);
+    }
+  }
+
+  // epilogue: lane = pixel, register quad q of tile ct = channels 32ct + 8q + 4h + 0..3
+  const int64_t gp = (int64_t)blockIdx.x * 128 + wave * 32 + l31;
+  if (gp < a.npix) {
+    const int co0 = blockIdx.y * (CT * 32);
+    float* orow = a.out + gp * a.cout + co0;
+    const float* rrow = a.res ? a.res + gp * a.cout + co0 : nullptr;
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int c = ct * 32 + 8 * q + 4 * h;
+        f32x4 v = {acc[ct][4 * q], acc[ct][4 * q + 1], acc[ct][4 * q + 2], acc[ct][4 * q + 3]};
+        if (a.bias) v += *(const f32x4*)(a.bias + co0 + c);
+        if (rrow) v += *(const f32x4*)(rrow + c);
+        if (a.relu) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.0f);
+        }
+        *(f32x4*)(orow + c) = v;
+      }
+  }
+}
+
+// One thread per output element (channel fastest): any channel counts, either memory order.
+__global__ void __launch_bounds__(256) cs_conv_direct_kernel(const CsConvArgs a) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= a.npix * a.cout) return;
+  const int co = (int)(idx % a.cout);
+  const int64_t gp = idx / a.cout;
+  const int hw = a.hout * a.wout;
+  const int64_t n = gp / hw;
+  const int rem = (int)(gp - n * hw);
+  const int oh = rem / a.wout, ow = rem - oh * a.wout;
+  const int hup = a.hin << a.us, wup = a.win << a.us;
+  const int kk = a.ksize * a.ksize;
+  float s = 0.0f;
+  for (int kh = 0; kh < a.ksize; ++kh) {
+    const int uh = oh * a.stride - a.pad + kh;
+    if (uh < 0 || uh >= hup) continue;
+    for (int kw = 0; kw < a.ksize; ++kw) {
+      const int uw = ow * a.stride - a.pad + kw;
+      if (uw < 0 || uw >= wup) continue;
+      const int sh = uh >> a.us, sw = uw >> a.us;
+      const float* wp = a.w + (int64_t)co * a.cin * kk + kh * a.ksize + kw;
+      if (a.in_nchw) {
+        const float* ip = a.in + (n * a.cin * a.hin + sh) * a.win + sw;
+        for (int ci = 0; ci < a.cin; ++ci) s = fmaf(ip[(int64_t)ci * a.hin * a.win], wp[(int64_t)ci * kk], s);
+      } else {
+        const float* ip = a.in + ((n * a.hin + sh) * a.win + sw) * a.cin;
+        for (int ci = 0; ci < a.cin; ++ci) s = fmaf(ip[ci], wp[(int64_t)ci * kk], s);
+      }
+    }
+  }
+  if (a.bias) s += a.bias[co];
+  if (a.res) s += a.res[gp * a.cout + co];
+  if (a.relu) s = fmaxf(s, 0.0f);
+  if (a.out_nchw) a.out[(n * a.cout + co) * hw + rem] = s;
+  else a.out[gp * a.cout + co] = s;
+}
+
+// AdaptiveAvgPool2d((1,1)) over NHWC: one thread per (row, channel).
+__global__ void __launch_bounds__(256) cs_avgpool_kernel(const float* in, float* out, int64_t n, int hw, int c) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= n * c) return;
+  const int64_t r = idx / c;
+  const int ch = (int)(idx - r * c);
+  const float* p = in + r * hw * c + ch;
+  float s = 0.0f;
+  for (int i = 0; i < hw; ++i) s += p[(int64_t)i * c];
+  out[idx] = s / (float)hw;
+}
+
+// F.interpolate(mode='nearest', size=...) over NHWC: src = min(floor(dst * (in/out)), in-1) with
+// the scale in float32, as torch computes it.
+__global__ void __launch_bounds__(256) cs_resize_kernel(const float* in, float* out, int64_t n, int hin, int win,
+                                                        int hout, int wout, int c) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= n * hout * wout * c) return;
+  const int ch = (int)(idx % c);
+  int64_t t = idx / c;
+  const int ow = (int)(t % wout);
+  t /= wout;
+  const int oh = (int)(t % hout);
+  const int64_t r = t / hout;
+  const float sh = (float)hin / (float)hout, sw = (float)win / (float)wout;
+  int ih = (int)floorf((float)oh * sh), iw = (int)floorf((float)ow * sw);
+  ih = ih < hin - 1 ? ih : hin - 1;
+  iw = iw < win - 1 ? iw : win - 1;
+  out[idx] = in[((r * hin + ih) * win + iw) * c + ch];
+}
+
+// ----------------------------------------------------------------------------------------
+// stage-in / finish kernels (rows are global row indices row0 + local)
+// ----------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) cs_gather_rows_kernel(const float* in, int64_t in_stride, const int64_t* in_off,
+                                                             int64_t row0, int64_t rows, int dim, float* out) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= rows * dim) return;
+  const int64_t r = idx / dim;
+  const int c = (int)(idx - r * dim);
+  const int64_t row = row0 + r;
+  out[idx] = in[(in_off ? in_off[row] : row * in_stride) + c];
+}
+
+// Z = loc + scale * eps (or the override row); one thread per 4 latent dimensions.
+__global__ void __launch_bounds__(256) cs_dec_stage_kernel(const CsMlpArgs a, int64_t row0, int64_t rows) {
+  const int Zd = a.Zd, nq = (Zd + 3) >> 2;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= rows * nq) return;
+  const int64_t row = row0 + idx / nq;
+  const int c0 = (int)(idx % nq) * 4;
+  const int64_t bk = row / a.Kp;
+  const int64_t kp = row - bk * a.Kp;
+  const int64_t b = bk % a.B;
+  const int64_t i = row / ((int64_t)a.Kp * a.B);
+  const float* qr = a.q + (b * a.Kp + kp) * 2 * Zd;
+  const bool ovr = a.z_override != nullptr && a.z_override[row] != 0;
+  f32x4 e = {0.f, 0.f, 0.f, 0.f};
+  if (a.eps_z == nullptr && !ovr) {
+    const int64_t prow = (a.rng.row_offset + b) * ((int64_t)a.I * a.Kp) + i * a.Kp + kp;
+    uint32_t x[4];
+    cs_philox_block(a.rng, CS_STREAM_Z, prow, (uint32_t)(c0 >> 2), x);
+    e = cs_normal4(x);
+  }
+  for (int r = 0; r < 4; ++r) {
+    const int c = c0 + r;
+    if (c >= Zd) break;
+    float z;
+    if (ovr) {
+      z = a.z_alt[row * Zd + c];
+    } else {
+      const float ev = a.eps_z ? a.eps_z[row * Zd + c] : e[r];
+      z = qr[c] + qr[Zd + c] * ev;
+    }
+    a.Z[row * Zd + c] = z;
+  }
+}
+
+// raw [rows, 2 Zd] -> q (loc, softplus(raw) (+1e-8)); replenishing rows (loc 0, scale 1).
+__global__ void __launch_bounds__(256) cs_enc_finish_kernel(const CsMlpArgs a, const float* raw, int64_t row0,
+                                                            int64_t rows) {
+  const int Zd = a.Zd;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= rows * Zd) return;
+  const int64_t r = idx / Zd;
+  const int z = (int)(idx - r * Zd);
+  const int64_t row = row0 + r;
+  const int64_t b = row / a.K;
+  const int64_t k = row - b * a.K;
+  float* qr = a.q + (b * a.Kp + k) * 2 * Zd;
+  float sc = cs_softplus(raw[r * 2 * Zd + Zd + z]);
+  if (a.latent_eps) sc += 1e-8f;
+  qr[z] = raw[r * 2 * Zd + z];
+  qr[Zd + z] = sc;
+  if (k == 0 && a.Kp > a.K) {
+    float* qp = a.q + (b * a.Kp + a.K) * 2 * Zd;
+    for (int t = z; t < (a.Kp - a.K) * 2 * Zd; t += Zd) qp[t] = ((t / Zd) & 1) ? 1.0f : 0.0f;
+  }
+}
+
+// raw [rows, P] -> generator parameters and the masked log-likelihood; one wavefront per row.
+__global__ void __launch_bounds__(64) cs_dec_finish_kernel(const CsMlpArgs a, const float* raw, int64_t row0) {
+  const int lane = threadIdx.x, D = a.D;
+  const int64_t r = blockIdx.x, row = row0 + r;
+  const int64_t bk = row / a.Kp;
+  const int64_t kp = row - bk * a.Kp;
+  const int64_t b = bk % a.B;
+  const bool want_ll = a.gen_ll != nullptr;
+  const int64_t xk = kp < a.K ? kp : 0;
+  const float* xr = want_ll ? a.X + (b * a.K + xk) * D : nullptr;
+  const uint8_t* mr = want_ll ? a.M + b * D : nullptr;
+  float ll = 0.0f;
+  if (a.gen_dist == CS_DIST_BERN) {
+    const float* pr = raw + r * D;
+    float* gr = a.gen + row * D;
+    for (int d = lane; d < D; d += 64) {
+      const float l = pr[d];
+      gr[d] = l;
+      if (want_ll) ll += cs_bernoulli_logpmf(xr[d], l) * (float)mr[d];
+    }
+  } else {
+    const float* pr = raw + r * 2 * D;
+    float* gr = a.gen + row * 2 * D;
+    const float eps = a.gen_dist == CS_DIST_NORMAL_WITH_EPS ? 1e-8f : 0.0f;
+    for (int d = lane; d < D; d += 64) {
+      const float mean = pr[d];
+      const float sc = cs_softplus(pr[D + d]) + eps;
+      gr[d] = mean;
+      gr[D + d] = sc;
+      if (want_ll) ll += cs_normal_logpdf(xr[d], mean, sc) * (float)mr[d];
+    }
+  }
+  if (want_ll) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ll += __shfl_xor(ll, o);
+    if (lane == 0) a.gen_ll[row] = ll;
+  }
+}
+
+inline unsigned blocks_for(int64_t n) { return (unsigned)((n + 255) / 256); }
+
+int launch_conv(const CsProgram& p, const CsLayer& L, const float* in, const float* res, float* out, int64_t rows,
+                hipStream_t stream) {
+  const cs_layer_desc& d = L.d;
+  CsConvArgs a;
+  a.in = in; a.res = res; a.out = out;
+  a.bias = d.b_off >= 0 ? p.d_blob + d.b_off : nullptr;
+  a.cin = d.cin; a.cout = d.cout; a.hin = d.hin; a.win = d.win; a.hout = d.hout; a.wout = d.wout;
+  a.ksize = d.ksize; a.stride = d.stride; a.pad = d.pad; a.us = d.upsample == 2 ? 1 : 0; a.relu = d.relu;
+  a.in_nchw = d.in_nchw; a.out_nchw = d.out_nchw;
+  a.npix = rows * d.hout * d.wout;
+  if (L.wp_off >= 0) {
+    a.w = p.d_blob + L.wp_off;
+    const unsigned gx = (unsigned)((a.npix + 127) / 128);
+    if (d.cout % 128 == 0)
+      hipLaunchKernelGGL(cs_conv_mfma_kernel<4>, dim3(gx, d.cout / 128), dim3(256), 0, stream, a);
+    else if (d.cout % 64 == 0)
+      hipLaunchKernelGGL(cs_conv_mfma_kernel<2>, dim3(gx, d.cout / 64), dim3(256), 0, stream, a);
+    else
+      hipLaunchKernelGGL(cs_conv_mfma_kernel<1>, dim3(gx, d.cout / 32), dim3(256), 0, stream, a);
+  } else {
+    a.w = p.d_blob + d.w_off;
+    hipLaunchKernelGGL(cs_conv_direct_kernel, dim3(blocks_for(a.npix * d.cout)), dim3(256), 0, stream, a);
+  }
+  CS_HIP(hipGetLastError());
+  return CS_OK;
+}
+
+bool mfma_eligible(const cs_layer_desc& d) {
+  return (d.op == CS_OP_CONV || d.op == CS_OP_LINEAR) && d.cin % 32 == 0 && d.cout % 32 == 0 && !d.in_nchw && !d.out_nchw;
+}
+
+constexpr int64_t kWorkspaceBudgetBytes = (int64_t)6 << 30;
+
+}  // namespace
+
+void cs_prog_destroy(CsProgram* p) {
+  if (!p) return;
+  if (p->d_blob) (void)hipFree(p->d_blob);
+  if (p->ws) (void)hipFree(p->ws);
+  delete p;
+}
+
+extern "C" int cs_net_create(const cs_layer_desc* layers, int32_t n_layers, const float* blob, int64_t blob_floats,
+                             int32_t in_dim, int32_t out_dim, int32_t out_split, cs_mlp_t** out) {
+  CS_REQUIRE(layers && blob && out, "null argument");
+  CS_REQUIRE(n_layers >= 1 && n_layers <= 4096, "bad layer count");
+  CS_REQUIRE(in_dim >= 1 && out_dim >= 1, "bad network dimensions");
+  CS_REQUIRE(out_split == 1 || out_split == 2, "out_split must be 1 or 2");
+  CS_REQUIRE(out_dim % out_split == 0, "out_dim not divisible by out_split");
+  CsProgram* p = new CsProgram();
+  p->in_dim = in_dim;
+  p->out_dim = out_dim;
+  p->buf_elems[CS_NET_BUF_IN] = in_dim;
+  p->buf_elems[CS_NET_BUF_OUT] = out_dim;
+  std::vector<float> packed;
+  auto fail = [&](const char* msg) {
+    delete p;
+    return cs_fail(CS_EINVAL, std::string("cs_net_create: ") + msg);
+  };
+  for (int i = 0; i < n_layers; ++i) {
+    cs_layer_desc d = layers[i];
+    if (d.op == CS_OP_LINEAR) {
+      d.hin = d.win = d.hout = d.wout = 1; d.ksize = 1; d.stride = 1; d.pad = 0; d.upsample = 1;
+      d.in_nchw = d.out_nchw = 0;
+    }
+    if (d.op < CS_OP_CONV || d.op > CS_OP_RESIZE) return fail("unknown op");
+    if (d.src < 0 || d.src >= CS_NET_NBUF || d.dst < 1 || d.dst >= CS_NET_NBUF || d.src == d.dst) return fail("bad buffer id");
+    if (d.res >= CS_NET_NBUF || d.res == d.dst) return fail("bad residual buffer id");
+    if (d.cin < 1 || d.cout < 1 || d.hin < 1 || d.win < 1 || d.hout < 1 || d.wout < 1) return fail("bad layer shape");
+    const int64_t in_elems = (int64_t)d.cin * d.hin * d.win, out_elems = (int64_t)d.cout * d.hout * d.wout;
+    if (d.op == CS_OP_CONV || d.op == CS_OP_LINEAR) {
+      if (d.ksize != 1 && d.ksize != 3) return fail("kernel size must be 1 or 3");
+      if (d.upsample != 1 && d.upsample != 2) return fail("upsample must be 1 or 2");
+      if (d.stride < 1) return fail("bad stride");
+      const int hup = d.hin * d.upsample, wup = d.win * d.upsample;
+      if ((hup + 2 * d.pad - d.ksize) / d.stride + 1 != d.hout || (wup + 2 * d.pad - d.ksize) / d.stride + 1 != d.wout)
+        return fail("convolution output size does not match");
+      const int64_t wn = (int64_t)d.cout * d.cin * d.ksize * d.ksize;
+      if (d.w_off < 0 || d.w_off + wn > blob_floats) return fail("weight offset out of range");
+      if (d.b_off >= 0 && d.b_off + d.cout > blob_floats) return fail("bias offset out of range");
+      if (d.res >= 0 && d.out_nchw) return fail("residual with a channel-major output");
+      if (mfma_eligible(d) && d.b_off >= 0 && d.b_off % 4 != 0) return fail("bias offsets of 32-multiple layers must be multiples of 4");
+    } else {
+      if (d.cin != d.cout) return fail("channel counts must match");
+      if (d.op == CS_OP_AVGPOOL && (d.hout != 1 || d.wout != 1)) return fail("average pool is global");
+      if (d.res >= 0 || d.relu) return fail("residual / ReLU only on convolutions");
+    }
+    if (d.src == CS_NET_BUF_IN ? in_elems != in_dim : in_elems > p->buf_elems[d.src]) return fail("source buffer not produced at this size");
+    if (d.res >= 0 && out_elems > p->buf_elems[d.res]) return fail("residual buffer not produced at this size");
+    if (d.dst == CS_NET_BUF_OUT) {
+      if (out_elems != out_dim) return fail("output layer size does not match out_dim");
+    } else if (out_elems > p->buf_elems[d.dst]) {
+      p->buf_elems[d.dst] = out_elems;
+    }
+    CsLayer L;
+    L.d = d;
+    L.wp_off = -1;
+    if (mfma_eligible(d)) {
+      // [tap][cin/32][cout][32]
+      L.wp_off = blob_floats + (int64_t)packed.size();
+      const int kk = d.ksize * d.ksize, ncc = d.cin / 32;
+      const float* W = blob + d.w_off;
+      for (int tap = 0; tap < kk; ++tap)
+        for (int cc = 0; cc < ncc; ++cc)
+          for (int co = 0; co < d.cout; ++co)
+            for (int c = 0; c < 32; ++c) packed.push_back(W[((int64_t)co * d.cin + cc * 32 + c) * kk + tap]);
+    }
+    p->layers.push_back(L);
+  }
+  if (p->layers.back().d.dst != CS_NET_BUF_OUT) return fail("the last layer must write the output buffer");
+
+  hipError_t e = hipGetDevice(&p->device);
+  if (e == hipSuccess) e = hipMalloc(&p->d_blob, (blob_floats + packed.size() + 4) * sizeof(float));
+  if (e == hipSuccess) e = hipMemcpy(p->d_blob, blob, blob_floats * sizeof(float), hipMemcpyHostToDevice);
+  if (e == hipSuccess && !packed.empty())
+    e = hipMemcpy(p->d_blob + blob_floats, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    cs_prog_destroy(p);
+    return cs_fail(CS_EHIP, std::string("cs_net_create: ") + hipGetErrorString(e));
+  }
+  cs_mlp* m = new cs_mlp();
+  std::memset(&m->desc, 0, sizeof(m->desc));
+  std::memset(&m->dev, 0, sizeof(m->dev));
+  m->desc.in_dim = in_dim; m->desc.out_dim = out_dim; m->desc.out_split = out_split;
+  m->d_w = nullptr; m->d_b = nullptr;
+  m->device = p->device;
+  m->prog = p;
+  m->dev.in_dim = in_dim; m->dev.out_dim = out_dim; m->dev.out_half = out_dim / out_split; m->dev.split = out_split;
+  m->dev.prog = p;
+  *out = m;
+  return CS_OK;
+}
+
+int cs_prog_launch(const CsMlpArgs& a, hipStream_t stream) {
+  CsProgram* p = (CsProgram*)a.net.prog;
+  int dev = 0;
+  CS_HIP(hipGetDevice(&dev));
+  CS_REQUIRE(dev == p->device, "network was created on another device");
+  if (a.mode == CS_MLP_DEC && a.gen_dist != CS_DIST_BERN)
+    CS_REQUIRE(a.net.split == 2 && a.net.out_dim == 2 * a.D, "generator output must be (mean | raw scale)");
+  if (a.mode == CS_MLP_DEC && a.gen_dist == CS_DIST_BERN) CS_REQUIRE(a.net.out_dim == a.D, "generator output must be D logits");
+  if (a.mode == CS_MLP_ENC) CS_REQUIRE(a.net.out_dim == 2 * a.Zd, "encoder output must be (loc | raw scale)");
+
+  // workspace: [staged input | scratch 1..4 | raw output] per row, for a chunk of rows
+  int64_t per_row = 0, prefix[CS_NET_NBUF];
+  for (int b = 0; b < CS_NET_NBUF; ++b) {
+    prefix[b] = per_row;
+    per_row += (p->buf_elems[b] + 3) & ~(int64_t)3;  // keep every buffer 16-byte aligned
+  }
+  int64_t chunk = kWorkspaceBudgetBytes / (per_row * 4);
+  if (chunk < 1) chunk = 1;
+  if (chunk > a.rows) chunk = a.rows;
+  chunk = (chunk + 3) & ~(int64_t)3;
+  if (chunk > p->ws_rows) {
+    if (p->ws) CS_HIP(hipFree(p->ws));  // waits for the work that still uses it
+    p->ws = nullptr;
+    p->ws_rows = 0;
+    CS_HIP(hipMalloc(&p->ws, (size_t)chunk * per_row * sizeof(float)));
+    p->ws_rows = chunk;
+  }
+  for (int64_t row0 = 0; row0 < a.rows; row0 += chunk) {
+    const int64_t rows = a.rows - row0 < chunk ? a.rows - row0 : chunk;
+    float* buf[CS_NET_NBUF];
+    for (int b = 0; b < CS_NET_NBUF; ++b) buf[b] = p->ws + prefix[b] * chunk;
+    const float* input;
+    if (a.mode == CS_MLP_DEC && a.in == nullptr) {
+      const int64_t n = rows * ((a.Zd + 3) / 4);
+      hipLaunchKernelGGL(cs_dec_stage_kernel, dim3(blocks_for(n)), dim3(256), 0, stream, a, row0, rows);
+      input = a.Z + row0 * a.Zd;
+    } else if (a.in_off == nullptr && a.in_stride == p->in_dim) {
+      input = a.in + row0 * p->in_dim;
+    } else {
+      hipLaunchKernelGGL(cs_gather_rows_kernel, dim3(blocks_for(rows * p->in_dim)), dim3(256), 0, stream, a.in,
+                         a.in_stride, a.in_off, row0, rows, p->in_dim, buf[CS_NET_BUF_IN]);
+      input = buf[CS_NET_BUF_IN];
+    }
+    float* raw = a.mode == CS_MLP_RAW ? a.out + row0 * p->out_dim : buf[CS_NET_BUF_OUT];
+    for (const CsLayer& L : p->layers) {
+      const cs_layer_desc& d = L.d;
+      const float* src = d.src == CS_NET_BUF_IN ? input : buf[d.src];
+      const float* res = d.res < 0 ? nullptr : (d.res == CS_NET_BUF_IN ? input : buf[d.res]);
+      float* dst = d.dst == CS_NET_BUF_OUT ? raw : buf[d.dst];
+      if (d.op == CS_OP_CONV || d.op == CS_OP_LINEAR) {
+        if (int rc = launch_conv(*p, L, src, res, dst, rows, stream)) return rc;
+      } else if (d.op == CS_OP_AVGPOOL) {
+        hipLaunchKernelGGL(cs_avgpool_kernel, dim3(blocks_for(rows * d.cin)), dim3(256), 0, stream, src, dst, rows,
+                           d.hin * d.win, d.cin);
+      } else {
+        hipLaunchKernelGGL(cs_resize_kernel, dim3(blocks_for(rows * d.hout * d.wout * d.cin)), dim3(256), 0, stream,
+                           src, dst, rows, d.hin, d.win, d.hout, d.wout, d.cin);
+      }
+    }
+    if (a.mode == CS_MLP_ENC)
+      hipLaunchKernelGGL(cs_enc_finish_kernel, dim3(blocks_for(rows * a.Zd)), dim3(256), 0, stream, a, raw, row0, rows);
+    else if (a.mode == CS_MLP_DEC)
+      hipLaunchKernelGGL(cs_dec_finish_kernel, dim3((unsigned)rows), dim3(64), 0, stream, a, raw, row0);
+    CS_HIP(hipGetLastError());
+  }
+  return CS_OK;
+}

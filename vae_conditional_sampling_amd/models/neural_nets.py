@@ -69,9 +69,27 @@ class ResidualFCNetwork(nn.Module):
                torch.cuda.current_device())
         if self._packed is None or self._packed_key != key:
             w = self.weight_dict()
-            self._packed = _lib.PackedMLP(w["W0"], w["b0"], w["blocks"], w["Wf"], w["bf"], self.out_split)
+            half = self.output_dim // self.out_split
+            if (self.residual_block_dim in (64, 128, 256) and self.input_dims <= 128
+                    and half <= (64 if self.out_split == 2 else 128)):
+                self._packed = _lib.PackedMLP(w["W0"], w["b0"], w["blocks"], w["Wf"], w["bf"], self.out_split)
+            else:
+                self._packed = self._layer_program(w)
             self._packed_key = key
         return self._packed
+
+    def _layer_program(self, w):
+        """Widths outside the fused kernel's range (e.g. the toy configuration's 512): one
+        matrix-core GEMM launch per layer, bias / residual / ReLU in its epilogue."""
+        b = _lib.ProgramBuilder(self.input_dims, self.output_dim, self.out_split)
+        cur, t, nxt = 1, 2, 3
+        b.linear(0, cur, w["W0"], w["b0"], relu=True)
+        for (W1, b1, W2, b2) in w["blocks"]:
+            b.linear(cur, t, W1, b1, relu=True)
+            b.linear(t, nxt, W2, b2, relu=True, res=cur)
+            cur, nxt = nxt, cur
+        b.linear(cur, _lib.CS_NET_BUF_OUT, w["Wf"], w["bf"])
+        return b.build()
 
     def forward(self, inputs: torch.Tensor):
         if self.training:

@@ -527,7 +527,8 @@ class TestVAEAdaptiveCollapsedMetropolisWithinGibbs(TestVAESamplerBase):
             d["u_res"] = src.uniform64(B * G, Kp // G)
         else:
             d["u_res"] = src.uniform(B, 1) if hp.resampling_scheme == 'gr' else src.uniform(B, G, 1)
-        d["eps_x"] = src.normal(B, Kw, D)
+        bern = self.model.hparams.generator_distribution.name == "bern"
+        d["eps_x"] = src.uniform(B, Kw, D) if bern else src.normal(B, Kw, D)
         return d
 
     def sampler(self, X, M):

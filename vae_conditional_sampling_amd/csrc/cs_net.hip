@@ -26,11 +26,13 @@ namespace {
 // ----------------------------------------------------------------------------------------
 struct CsConvArgs {
   const float* in;    // [n, hin, win, cin]
-  const float* w;     // packed [tap][cin/32][cout][32] (mfma) or torch [cout][cin][k][k] (direct)
+  const float* w;     // packed [tap][cin_p/32][cout_p][32] (mfma; _p = padded to 32, zero filled) or
+                      // torch [cout][cin][k][k] (direct)
   const float* bias;  // [cout] or null
   const float* res;   // [n, hout, wout, cout] or null
   float* out;
   int cin, cout, hin, win, hout, wout, ksize, stride, pad, us, relu, in_nchw, out_nchw;
+  int cout_p;    // cout rounded up to 32 (mfma)
   int64_t npix;  // n * hout * wout
 };
 
@@ -41,7 +43,9 @@ struct CsConvArgs {
 // both tiles sit in LDS as [row][32 k] (row stride 36 floats), and each lane reads 4 consecutive
 // k with one ds_read_b128: within a group of 8 k, MFMA step j uses k = 4*(lane>>5) + j on both
 // operands, which covers the 8 values once.  The next chunk is fetched into registers while the
-// current one is multiplied.
+// current one is multiplied.  Channel counts that are not multiples of 32 are zero padded in the
+// packed weights; the activation loads and the stores of such layers take a guarded scalar path
+// (the decoder's first linear layer, the last convolution to 1-2 channels in either memory order).
 template <int CT>
 __global__ void __launch_bounds__(256) cs_conv_mfma_kernel(const CsConvArgs a) {
   constexpr int RS = 36;
@@ -50,7 +54,8 @@ __global__ void __launch_bounds__(256) cs_conv_mfma_kernel(const CsConvArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = lane >> 5, l31 = lane & 31;
   const int c4 = tid & 7;
-  const int ncc = a.cin >> 5;
+  const int ncc = (a.cin + 31) >> 5;
+  const bool cin_vec = (a.cin & 31) == 0;
   const int nchunks = a.ksize * a.ksize * ncc;
   const int hup = a.hin << a.us, wup = a.win << a.us;
 
@@ -81,11 +86,20 @@ __global__ void __launch_bounds__(256) cs_conv_mfma_kernel(const CsConvArgs a) {
     for (int p = 0; p < 4; ++p) {
       const int uh = ih0[p] + kh, uw = iw0[p] + kw;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (pv[p] && uh >= 0 && uh < hup && uw >= 0 && uw < wup)
-        v = *(const f32x4*)(a.in + ((base[p] + (int64_t)(uh >> a.us) * a.win + (uw >> a.us)) * a.cin + cc * 32 + c4 * 4));
+      if (pv[p] && uh >= 0 && uh < hup && uw >= 0 && uw < wup) {
+        const int c0 = cc * 32 + c4 * 4;
+        const float* src = a.in + ((base[p] + (int64_t)(uh >> a.us) * a.win + (uw >> a.us)) * a.cin + c0);
+        if (cin_vec) {
+          v = *(const f32x4*)src;
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (c0 + r < a.cin) v[r] = src[r];
+        }
+      }
       rp[p] = v;
     }
-    const float* wt = wblk + (int64_t)t * a.cout * 32;
+    const float* wt = wblk + (int64_t)t * a.cout_p * 32;
 #pragma unroll
     for (int i = 0; i < CT; ++i) rw[i] = *(const f32x4*)(wt + (tid + 256 * i) * 4);
   };
@@ -128,38 +142,65 @@ __global__ void __launch_bounds__(256) cs_conv_mfma_kernel(const CsConvArgs a) {
   const int64_t gp = (int64_t)blockIdx.x * 128 + wave * 32 + l31;
   if (gp < a.npix) {
     const int co0 = blockIdx.y * (CT * 32);
-    float* orow = a.out + gp * a.cout + co0;
-    const float* rrow = a.res ? a.res + gp * a.cout + co0 : nullptr;
+    if ((a.cout & 31) == 0 && !a.out_nchw) {
+      float* orow = a.out + gp * a.cout + co0;
+      const float* rrow = a.res ? a.res + gp * a.cout + co0 : nullptr;
 #pragma unroll
-    for (int ct = 0; ct < CT; ++ct)
+      for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int c = ct * 32 + 8 * q + 4 * h;
-        f32x4 v = {acc[ct][4 * q], acc[ct][4 * q + 1], acc[ct][4 * q + 2], acc[ct][4 * q + 3]};
-        if (a.bias) v += *(const f32x4*)(a.bias + co0 + c);
-        if (rrow) v += *(const f32x4*)(rrow + c);
-        if (a.relu) {
+        for (int q = 0; q < 4; ++q) {
+          const int c = ct * 32 + 8 * q + 4 * h;
+          f32x4 v = {acc[ct][4 * q], acc[ct][4 * q + 1], acc[ct][4 * q + 2], acc[ct][4 * q + 3]};
+          if (a.bias) v += *(const f32x4*)(a.bias + co0 + c);
+          if (rrow) v += *(const f32x4*)(rrow + c);
+          if (a.relu) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.0f);
+            for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.0f);
+          }
+          *(f32x4*)(orow + c) = v;
         }
-        *(f32x4*)(orow + c) = v;
-      }
+    } else {
+      const int hw = a.hout * a.wout;
+      const int64_t n = gp / hw;
+      const int rem = (int)(gp - n * hw);
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int co = co0 + ct * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
+          if (co < a.cout) {
+            float v = acc[ct][r];
+            if (a.bias) v += a.bias[co];
+            if (a.res) v += a.res[gp * a.cout + co];
+            if (a.relu) v = fmaxf(v, 0.0f);
+            if (a.out_nchw) a.out[(n * a.cout + co) * hw + rem] = v;
+            else a.out[gp * a.cout + co] = v;
+          }
+        }
+    }
   }
 }
 
-// One thread per output element (channel fastest): any channel counts, either memory order.
+// V output channels per thread (channel fastest): any channel counts, either memory order.  V = 4
+// (cout % 4 == 0, NHWC output) stores 16 bytes per thread: the layers that land here are bound by
+// their output writes.
+template <int V>
 __global__ void __launch_bounds__(256) cs_conv_direct_kernel(const CsConvArgs a) {
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= a.npix * a.cout) return;
-  const int co = (int)(idx % a.cout);
-  const int64_t gp = idx / a.cout;
+  const int cv = a.cout / V;
+  if (idx >= a.npix * cv) return;
+  const int co = (int)(idx % cv) * V;
+  const int64_t gp = idx / cv;
   const int hw = a.hout * a.wout;
   const int64_t n = gp / hw;
   const int rem = (int)(gp - n * hw);
   const int oh = rem / a.wout, ow = rem - oh * a.wout;
   const int hup = a.hin << a.us, wup = a.win << a.us;
   const int kk = a.ksize * a.ksize;
-  float s = 0.0f;
+  const int64_t wstride = (int64_t)a.cin * kk;  // between output channels
+  float s[V];
+#pragma unroll
+  for (int v = 0; v < V; ++v) s[v] = 0.0f;
   for (int kh = 0; kh < a.ksize; ++kh) {
     const int uh = oh * a.stride - a.pad + kh;
     if (uh < 0 || uh >= hup) continue;
@@ -167,21 +208,30 @@ __global__ void __launch_bounds__(256) cs_conv_direct_kernel(const CsConvArgs a)
       const int uw = ow * a.stride - a.pad + kw;
       if (uw < 0 || uw >= wup) continue;
       const int sh = uh >> a.us, sw = uw >> a.us;
-      const float* wp = a.w + (int64_t)co * a.cin * kk + kh * a.ksize + kw;
-      if (a.in_nchw) {
-        const float* ip = a.in + (n * a.cin * a.hin + sh) * a.win + sw;
-        for (int ci = 0; ci < a.cin; ++ci) s = fmaf(ip[(int64_t)ci * a.hin * a.win], wp[(int64_t)ci * kk], s);
-      } else {
-        const float* ip = a.in + ((n * a.hin + sh) * a.win + sw) * a.cin;
-        for (int ci = 0; ci < a.cin; ++ci) s = fmaf(ip[ci], wp[(int64_t)ci * kk], s);
+      const float* wp = a.w + (int64_t)co * wstride + kh * a.ksize + kw;
+      const float* ip = a.in_nchw ? a.in + (n * a.cin * a.hin + sh) * a.win + sw : a.in + ((n * a.hin + sh) * a.win + sw) * a.cin;
+      const int64_t istride = a.in_nchw ? (int64_t)a.hin * a.win : 1;
+      for (int ci = 0; ci < a.cin; ++ci) {
+        const float x = ip[ci * istride];
+#pragma unroll
+        for (int v = 0; v < V; ++v) s[v] = fmaf(x, wp[v * wstride + (int64_t)ci * kk], s[v]);
       }
     }
   }
-  if (a.bias) s += a.bias[co];
-  if (a.res) s += a.res[gp * a.cout + co];
-  if (a.relu) s = fmaxf(s, 0.0f);
-  if (a.out_nchw) a.out[(n * a.cout + co) * hw + rem] = s;
-  else a.out[gp * a.cout + co] = s;
+#pragma unroll
+  for (int v = 0; v < V; ++v) {
+    if (a.bias) s[v] += a.bias[co + v];
+    if (a.res) s[v] += a.res[gp * a.cout + co + v];
+    if (a.relu) s[v] = fmaxf(s[v], 0.0f);
+  }
+  if (V == 4) {
+    const f32x4 o = {s[0], s[V > 1 ? 1 : 0], s[V > 2 ? 2 : 0], s[V > 3 ? 3 : 0]};
+    *(f32x4*)(a.out + gp * a.cout + co) = o;
+  } else if (a.out_nchw) {
+    a.out[(n * a.cout + co) * hw + rem] = s[0];
+  } else {
+    a.out[gp * a.cout + co] = s[0];
+  }
 }
 
 // AdaptiveAvgPool2d((1,1)) over NHWC: one thread per (row, channel).
@@ -335,25 +385,32 @@ int launch_conv(const CsProgram& p, const CsLayer& L, const float* in, const flo
   a.ksize = d.ksize; a.stride = d.stride; a.pad = d.pad; a.us = d.upsample == 2 ? 1 : 0; a.relu = d.relu;
   a.in_nchw = d.in_nchw; a.out_nchw = d.out_nchw;
   a.npix = rows * d.hout * d.wout;
+  a.cout_p = (d.cout + 31) & ~31;
   if (L.wp_off >= 0) {
     a.w = p.d_blob + L.wp_off;
     const unsigned gx = (unsigned)((a.npix + 127) / 128);
-    if (d.cout % 128 == 0)
-      hipLaunchKernelGGL(cs_conv_mfma_kernel<4>, dim3(gx, d.cout / 128), dim3(256), 0, stream, a);
-    else if (d.cout % 64 == 0)
-      hipLaunchKernelGGL(cs_conv_mfma_kernel<2>, dim3(gx, d.cout / 64), dim3(256), 0, stream, a);
+    if (a.cout_p % 128 == 0)
+      hipLaunchKernelGGL(cs_conv_mfma_kernel<4>, dim3(gx, a.cout_p / 128), dim3(256), 0, stream, a);
+    else if (a.cout_p % 64 == 0)
+      hipLaunchKernelGGL(cs_conv_mfma_kernel<2>, dim3(gx, a.cout_p / 64), dim3(256), 0, stream, a);
     else
-      hipLaunchKernelGGL(cs_conv_mfma_kernel<1>, dim3(gx, d.cout / 32), dim3(256), 0, stream, a);
+      hipLaunchKernelGGL(cs_conv_mfma_kernel<1>, dim3(gx, a.cout_p / 32), dim3(256), 0, stream, a);
   } else {
     a.w = p.d_blob + d.w_off;
-    hipLaunchKernelGGL(cs_conv_direct_kernel, dim3(blocks_for(a.npix * d.cout)), dim3(256), 0, stream, a);
+    if (d.cout % 4 == 0 && !d.out_nchw)
+      hipLaunchKernelGGL(cs_conv_direct_kernel<4>, dim3(blocks_for(a.npix * (d.cout / 4))), dim3(256), 0, stream, a);
+    else
+      hipLaunchKernelGGL(cs_conv_direct_kernel<1>, dim3(blocks_for(a.npix * d.cout)), dim3(256), 0, stream, a);
   }
   CS_HIP(hipGetLastError());
   return CS_OK;
 }
 
+// The matrix-core kernel takes every convolution / linear layer whose contraction is worth padding
+// to 32 channels: all but layers reading very few channels (the first convolution from a 1-channel
+// image is bound by its output writes, not by arithmetic) or a channel-major multi-channel input.
 bool mfma_eligible(const cs_layer_desc& d) {
-  return (d.op == CS_OP_CONV || d.op == CS_OP_LINEAR) && d.cin % 32 == 0 && d.cout % 32 == 0 && !d.in_nchw && !d.out_nchw;
+  return (d.op == CS_OP_CONV || d.op == CS_OP_LINEAR) && d.cin >= 16 && !(d.in_nchw && d.cin > 1);
 }
 
 constexpr int64_t kWorkspaceBudgetBytes = (int64_t)6 << 30;
@@ -406,7 +463,7 @@ extern "C" int cs_net_create(const cs_layer_desc* layers, int32_t n_layers, cons
       if (d.w_off < 0 || d.w_off + wn > blob_floats) return fail("weight offset out of range");
       if (d.b_off >= 0 && d.b_off + d.cout > blob_floats) return fail("bias offset out of range");
       if (d.res >= 0 && d.out_nchw) return fail("residual with a channel-major output");
-      if (mfma_eligible(d) && d.b_off >= 0 && d.b_off % 4 != 0) return fail("bias offsets of 32-multiple layers must be multiples of 4");
+      if (d.b_off >= 0 && d.b_off % 4 != 0) return fail("bias offsets must be multiples of 4 floats");
     } else {
       if (d.cin != d.cout) return fail("channel counts must match");
       if (d.op == CS_OP_AVGPOOL && (d.hout != 1 || d.wout != 1)) return fail("average pool is global");
@@ -423,14 +480,17 @@ extern "C" int cs_net_create(const cs_layer_desc* layers, int32_t n_layers, cons
     L.d = d;
     L.wp_off = -1;
     if (mfma_eligible(d)) {
-      // [tap][cin/32][cout][32]
+      // [tap][cin_p/32][cout_p][32], zero padded
       L.wp_off = blob_floats + (int64_t)packed.size();
-      const int kk = d.ksize * d.ksize, ncc = d.cin / 32;
+      const int kk = d.ksize * d.ksize, ncc = (d.cin + 31) / 32, cout_p = (d.cout + 31) & ~31;
       const float* W = blob + d.w_off;
       for (int tap = 0; tap < kk; ++tap)
         for (int cc = 0; cc < ncc; ++cc)
-          for (int co = 0; co < d.cout; ++co)
-            for (int c = 0; c < 32; ++c) packed.push_back(W[((int64_t)co * d.cin + cc * 32 + c) * kk + tap]);
+          for (int co = 0; co < cout_p; ++co)
+            for (int c = 0; c < 32; ++c) {
+              const int ci = cc * 32 + c;
+              packed.push_back(co < d.cout && ci < d.cin ? W[((int64_t)co * d.cin + ci) * kk + tap] : 0.0f);
+            }
     }
     p->layers.push_back(L);
   }

@@ -46,11 +46,13 @@ struct CsConvArgs {
 // current one is multiplied.  Channel counts that are not multiples of 32 are zero padded in the
 // packed weights; the activation loads and the stores of such layers take a guarded scalar path
 // (the decoder's first linear layer, the last convolution to 1-2 channels in either memory order).
-template <int CT>
+template <int CT, int PT>
 __global__ void __launch_bounds__(256) cs_conv_mfma_kernel(const CsConvArgs a) {
   constexpr int RS = 36;
-  __shared__ __attribute__((aligned(16))) float s_pix[128 * RS];
-  __shared__ __attribute__((aligned(16))) float s_w[CT * 32 * RS];
+  constexpr int NPIX = 128 * PT;  // output pixels per block; a wavefront owns 32 * PT of them
+  extern __shared__ __attribute__((aligned(16))) float s_dyn[];
+  float* s_pix = s_dyn;              // [NPIX][RS]
+  float* s_w = s_dyn + NPIX * RS;    // [CT*32][RS]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = lane >> 5, l31 = lane & 31;
   const int c4 = tid & 7;
@@ -59,13 +61,13 @@ __global__ void __launch_bounds__(256) cs_conv_mfma_kernel(const CsConvArgs a) {
   const int nchunks = a.ksize * a.ksize * ncc;
   const int hup = a.hin << a.us, wup = a.win << a.us;
 
-  // the 4 activation rows this thread stages
-  int ih0[4], iw0[4];
-  int64_t base[4];
-  bool pv[4];
+  // the 4*PT activation rows this thread stages
+  int ih0[4 * PT], iw0[4 * PT];
+  int64_t base[4 * PT];
+  bool pv[4 * PT];
 #pragma unroll
-  for (int p = 0; p < 4; ++p) {
-    const int64_t gp = (int64_t)blockIdx.x * 128 + (tid >> 3) + 32 * p;
+  for (int p = 0; p < 4 * PT; ++p) {
+    const int64_t gp = (int64_t)blockIdx.x * NPIX + (tid >> 3) + 32 * p;
     pv[p] = gp < a.npix;
     const int64_t g = pv[p] ? gp : 0;
     const int hw = a.hout * a.wout;
@@ -78,12 +80,19 @@ __global__ void __launch_bounds__(256) cs_conv_mfma_kernel(const CsConvArgs a) {
   }
   const float* wblk = a.w + (int64_t)blockIdx.y * (CT * 32) * 32;
 
-  f32x4 rp[4], rw[CT];
+  f32x16 acc[PT][CT];
+#pragma unroll
+  for (int pt = 0; pt < PT; ++pt)
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[pt][ct][r] = 0.0f;
+  f32x4 rp[4 * PT], rw[CT];
   auto fetch = [&](int t) {
     const int tap = t / ncc, cc = t - tap * ncc;
     const int kh = tap / a.ksize, kw = tap - kh * a.ksize;
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
+    for (int p = 0; p < 4 * PT; ++p) {
       const int uh = ih0[p] + kh, uw = iw0[p] + kw;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if (pv[p] && uh >= 0 && uh < hup && uw >= 0 && uw < wup) {
@@ -105,7 +114,7 @@ __global__ void __launch_bounds__(256) cs_conv_mfma_kernel(const CsConvArgs a) {
   };
   auto stash = [&]() {
 #pragma unroll
-    for (int p = 0; p < 4; ++p) *(f32x4*)(s_pix + ((tid >> 3) + 32 * p) * RS + c4 * 4) = rp[p];
+    for (int p = 0; p < 4 * PT; ++p) *(f32x4*)(s_pix + ((tid >> 3) + 32 * p) * RS + c4 * 4) = rp[p];
 #pragma unroll
     for (int i = 0; i < CT; ++i) {
       const int idx = tid + 256 * i;
@@ -113,13 +122,11 @@ __global__ void __launch_bounds__(256) cs_conv_mfma_kernel(const CsConvArgs a) {
     }
   };
 
-  f32x16 acc[CT];
-#pragma unroll
-  for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[ct][r] = 0.0f;
-
+  // One LDS stage; the next chunk waits in registers while this one is multiplied.  (Two LDS
+  // stages with one barrier per chunk were measured slower: fewer blocks fit a CU.)
   fetch(0);
+  const float* sp = s_pix + (wave * 32 * PT + l31) * RS + 4 * h;
+  const float* sw = s_w + l31 * RS + 4 * h;
   for (int t = 0; t < nchunks; ++t) {
     __syncthreads();  // previous chunk's reads are done
     stash();
@@ -127,20 +134,26 @@ __global__ void __launch_bounds__(256) cs_conv_mfma_kernel(const CsConvArgs a) {
     if (t + 1 < nchunks) fetch(t + 1);
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      const f32x4 b = *(const f32x4*)(s_pix + (wave * 32 + l31) * RS + 8 * g + 4 * h);
-      f32x4 w[CT];
+      f32x4 b[PT], w[CT];
 #pragma unroll
-      for (int ct = 0; ct < CT; ++ct) w[ct] = *(const f32x4*)(s_w + (ct * 32 + l31) * RS + 8 * g + 4 * h);
+      for (int pt = 0; pt < PT; ++pt) b[pt] = *(const f32x4*)(sp + pt * 32 * RS + 8 * g);
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) w[ct] = *(const f32x4*)(sw + ct * 32 * RS + 8 * g);
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[ct][j], b[j], acc[ct], 0, 0, 0);
+        for (int pt = 0; pt < PT; ++pt)
+#pragma unroll
+          for (int ct = 0; ct < CT; ++ct)
+            acc[pt][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[ct][j], b[pt][j], acc[pt][ct], 0, 0, 0);
     }
   }
 
   // epilogue: lane = pixel, register quad q of tile ct = channels 32ct + 8q + 4h + 0..3
-  const int64_t gp = (int64_t)blockIdx.x * 128 + wave * 32 + l31;
-  if (gp < a.npix) {
+#pragma unroll
+  for (int pt = 0; pt < PT; ++pt) {
+    const int64_t gp = (int64_t)blockIdx.x * NPIX + wave * 32 * PT + pt * 32 + l31;
+    if (gp >= a.npix) continue;
     const int co0 = blockIdx.y * (CT * 32);
     if ((a.cout & 31) == 0 && !a.out_nchw) {
       float* orow = a.out + gp * a.cout + co0;
@@ -150,7 +163,7 @@ __global__ void __launch_bounds__(256) cs_conv_mfma_kernel(const CsConvArgs a) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int c = ct * 32 + 8 * q + 4 * h;
-          f32x4 v = {acc[ct][4 * q], acc[ct][4 * q + 1], acc[ct][4 * q + 2], acc[ct][4 * q + 3]};
+          f32x4 v = {acc[pt][ct][4 * q], acc[pt][ct][4 * q + 1], acc[pt][ct][4 * q + 2], acc[pt][ct][4 * q + 3]};
           if (a.bias) v += *(const f32x4*)(a.bias + co0 + c);
           if (rrow) v += *(const f32x4*)(rrow + c);
           if (a.relu) {
@@ -169,7 +182,7 @@ __global__ void __launch_bounds__(256) cs_conv_mfma_kernel(const CsConvArgs a) {
         for (int r = 0; r < 16; ++r) {
           const int co = co0 + ct * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
           if (co < a.cout) {
-            float v = acc[ct][r];
+            float v = acc[pt][ct][r];
             if (a.bias) v += a.bias[co];
             if (a.res) v += a.res[gp * a.cout + co];
             if (a.relu) v = fmaxf(v, 0.0f);
@@ -388,13 +401,19 @@ int launch_conv(const CsProgram& p, const CsLayer& L, const float* in, const flo
   a.cout_p = (d.cout + 31) & ~31;
   if (L.wp_off >= 0) {
     a.w = p.d_blob + L.wp_off;
-    const unsigned gx = (unsigned)((a.npix + 127) / 128);
-    if (a.cout_p % 128 == 0)
-      hipLaunchKernelGGL(cs_conv_mfma_kernel<4>, dim3(gx, a.cout_p / 128), dim3(256), 0, stream, a);
-    else if (a.cout_p % 64 == 0)
-      hipLaunchKernelGGL(cs_conv_mfma_kernel<2>, dim3(gx, a.cout_p / 64), dim3(256), 0, stream, a);
-    else
-      hipLaunchKernelGGL(cs_conv_mfma_kernel<1>, dim3(gx, a.cout_p / 32), dim3(256), 0, stream, a);
+#define CS_CONV_LAUNCH(CT_)                                                                               \
+  do {                                                                                                    \
+    const size_t lds = (size_t)(128 + CT_ * 32) * 36 * sizeof(float);                                     \
+    const unsigned gx = (unsigned)((a.npix + 127) / 128);                                                 \
+    hipLaunchKernelGGL((cs_conv_mfma_kernel<CT_, 1>), dim3(gx, a.cout_p / (32 * CT_)), dim3(256), lds,    \
+                       stream, a);                                                                        \
+  } while (0)
+    // Measured on the Omniglot / MNIST-GMM nets: 128-pixel x 128-channel blocks (two blocks per CU)
+    // beat 256-pixel blocks, 64-channel blocks and a two-stage LDS ring by 2-7 %.
+    if (a.cout_p % 128 == 0) CS_CONV_LAUNCH(4);
+    else if (a.cout_p % 64 == 0) CS_CONV_LAUNCH(2);
+    else CS_CONV_LAUNCH(1);
+#undef CS_CONV_LAUNCH
   } else {
     a.w = p.d_blob + d.w_off;
     if (d.cout % 4 == 0 && !d.out_nchw)

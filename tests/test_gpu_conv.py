@@ -112,3 +112,31 @@ def test_acmwg_sampler_conv_bernoulli_matches_reference_golden():
     for t, o in enumerate(outs):
         assert np.array_equal(o["X"].cpu().numpy(), fx["X_seq"][t].astype(np.float32)), f"binary imputations differ at {t}"
     assert_close(outs[-1]["Z"], fx["Z_last"], "Z", CONV_RTOL)
+
+
+def test_yaml_driver_end_to_end_conv_configs(tmp_path):
+    """Omniglot AC-MWG and MNIST-GMM LAIR YAML configurations (full-size nets, random weights,
+    synthetic data, a few iterations) through the driver."""
+    import os
+    from tests.helpers import ROOT
+    from vae_conditional_sampling_amd import driver
+    cfg = driver.load_config(os.path.join(ROOT, "configs/omniglot28x28_bin/q50/acmwg_k5_005prior_irwg_warmup.yaml"),
+                             ["data.synthetic_num_test=12", "data.batch_size=8", f"trainer.default_root_dir={tmp_path}",
+                              "test_class.init_args.num_pseudo_warmup_iterations=2",
+                              "test_class.init_args.num_mwg_iterations=5", "test_class.init_args.store_last_n_iterations=-1"])
+    tester, outs = driver.run(cfg)
+    g0 = np.load(os.path.join(tester.out_dir, "imputations_0.npz"))
+    assert g0["imputations"].shape == (1 + 2 * 4 + 5, 8, 5, 784)
+    assert set(np.unique(g0["imputations"]).tolist()) <= {0.0, 1.0}
+    obs = np.broadcast_to(g0["masks"], (8, 5, 784))
+    for t in range(g0["imputations"].shape[0]):
+        assert np.array_equal(g0["imputations"][t][obs], np.broadcast_to(g0["true_X"], (8, 5, 784))[obs])
+    assert all(0.0 <= a <= 1.0 for a in outs[0]["acceptance"])
+
+    cfg = driver.load_config(os.path.join(ROOT, "configs/mnist_gmm/samples/lair_k4_dmis_gr_mult_replenish1_finalresample.yaml"),
+                             [f"trainer.default_root_dir={tmp_path}", "test_class.init_args.num_iterations=4"])
+    tester, outs = driver.run(cfg)
+    f0 = np.load(os.path.join(tester.out_dir, "imputations_0.npz"))
+    assert f0["imputations"].shape == (5, 10, 4, 196) and np.isfinite(f0["imputations"]).all()
+    f1 = np.load(os.path.join(tester.out_dir, "irwg_imputations_after_final_resampling_0.npz"))
+    assert f1["imputations"].shape == (1, 10, 4 * 5, 196) and np.isfinite(f1["imputations"]).all()

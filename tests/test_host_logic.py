@@ -109,3 +109,40 @@ def test_uniform_mask_has_exact_missing_count():
     assert int((~m).sum()) == 350
     assert [shard_range(10, r, 4) for r in range(4)] == [(0, 3), (3, 6), (6, 8), (8, 10)]
     assert shard_range(0, 0, 2) == (0, 0)
+
+
+def test_resnet_modules_mirror_reference_state_dict_layout():
+    """The oracle's weight dicts use the reference's key names (pinned by a strict load into the
+    reference modules when the fixtures were made); the product modules must accept them strictly."""
+    from oracle import cs_oracle_conv as OC
+    from tests.helpers import CONV_NETS
+    from vae_conditional_sampling_amd.models.vae_resnet import ResNetDecoder, ResNetEncoder
+    for name, n in CONV_NETS.items():
+        enc_w = OC.make_resnet_encoder_weights(seed=1, **n["enc"])
+        dec_w = OC.make_resnet_decoder_weights(seed=2, **n["dec"])
+        enc, dec = ResNetEncoder(**n["enc"]), ResNetDecoder(**n["dec"])
+        enc.load_state_dict(OC.state_dict_of(enc_w), strict=True)
+        dec.load_state_dict(OC.state_dict_of(dec_w), strict=True)
+        assert enc.input_dim == int(np.prod(n["enc"]["input_shape"])) and enc.output_dim == n["enc"]["latent_dim"]
+        assert dec.input_dim == n["dec"]["latent_dim"] and dec.output_dim == int(np.prod(n["dec"]["output_shape"]))
+    keys = set(dec.state_dict().keys())
+    assert "layers.0.0.conv2.1.weight" in keys and "layers.0.0.upsample.0.1.weight" in keys
+    assert "layers.3.0.conv2.weight" in keys and "layers.0.0.upsample.1.running_var" in keys
+    with pytest.raises(NotImplementedError):
+        ResNetEncoder((1, 28, 28), [1], [32], 8, first_conv=True)
+
+
+def test_quadrant_and_nan_missingness():
+    from vae_conditional_sampling_amd.data import MissingDataModule
+    from vae_conditional_sampling_amd.data.missing_data_module import quadrant_missingness_mask
+    g = torch.Generator().manual_seed(3)
+    M = quadrant_missingness_mask(50, (28, 28), 0.5, g).reshape(50, 28, 28)
+    for b in range(50):
+        quads = [M[b, r:r + 14, c:c + 14] for r in (0, 14) for c in (0, 14)]
+        assert sorted(int(q.all()) for q in quads) == [0, 0, 1, 1]          # two quadrants fully observed
+        assert sorted(int((~q).all()) for q in quads) == [0, 0, 1, 1]       # two fully missing
+    assert quadrant_missingness_mask(4, (28, 28), 0.0, g).all()
+    dm = MissingDataModule("mnist_gmm_custtest0", 20, missingness="nan_miss", synthetic=True, setup_seed=5)
+    dm.setup("test")
+    X, Mb, I = next(iter(dm.test_dataloader()))
+    assert X.shape == (10, 196) and torch.equal(Mb, ~torch.isnan(X)) and Mb[:, :98].all() and not Mb[:, 98:].any()

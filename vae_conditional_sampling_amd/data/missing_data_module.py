@@ -2,8 +2,8 @@
 
 Counterpart of ``MissingDataModule`` (irwg/data/missing_data_module.py:187-470) restricted to
 what the sampling driver needs: ``setup('test')`` builds the test split, applies the
-missingness pattern, optionally drops fully-missing rows, appends the data index and keeps the
-first ``num_first_datapoints_test`` points; ``test_dataloader()`` yields
+missingness pattern (``uniform``, image ``quadrants`` or ``nan_miss``), optionally drops
+fully-missing rows, appends the data index and keeps the first ``num_first_datapoints_test`` points; ``test_dataloader()`` yields
 ``(X float32 [B,D], M bool [B,D] (True = observed), I int64 [B])`` in order (no shuffling).
 
 Datasets: a ``.npy`` file ``{data_root}/{dataset}/test.npy`` when present; otherwise, when
@@ -23,9 +23,11 @@ import torch
 
 from ..utils.hparams import AttrDict
 
-DATASET_DIMS = {"uci_miniboone": 43, "uci_hepmass": 21, "uci_gas": 8, "uci_power": 6, "toy_grid2dmog4": 2}
+DATASET_DIMS = {"uci_miniboone": 43, "uci_hepmass": 21, "uci_gas": 8, "uci_power": 6, "toy_grid2dmog4": 2,
+                "omniglot28x28_fbin": 784, "mnist_gmm": 196, "mnist_gmm_custtest0": 196}
 DATASET_TEST_SIZES = {"uci_miniboone": 3648, "uci_hepmass": 174987, "uci_gas": 105206, "uci_power": 204928,
-                      "toy_grid2dmog4": 14}
+                      "toy_grid2dmog4": 14, "omniglot28x28_fbin": 8070, "mnist_gmm": 10, "mnist_gmm_custtest0": 10}
+BINARY_DATASETS = ("omniglot28x28_fbin",)  # synthetic stand-in: Bernoulli(0.2) pixels
 
 
 def uniform_missingness_mask(shape, total_miss, rng):
@@ -36,6 +38,22 @@ def uniform_missingness_mask(shape, total_miss, rng):
     mask[:int(total_miss * total)] = 0
     perm = torch.randperm(total, generator=rng)
     return mask[perm].reshape(*shape)
+
+
+def quadrant_missingness_mask(n, img_dims, total_miss, rng):
+    """``int(total_miss * 4)`` of the four image quadrants missing per example, drawn without
+    replacement (irwg/data/quadrant_missingness_provider.py:57-74).  True = observed."""
+    assert total_miss in (0., 0.25, 0.5, 0.75), "Missingness fraction can only be 0., 0.25, 0.5, or 0.75!"
+    H, W = int(img_dims[0]), int(img_dims[1])
+    mask = torch.ones(n, H, W, dtype=torch.bool)
+    if total_miss > 0.:
+        q = torch.multinomial(torch.ones(n, 4), num_samples=int(total_miss * 4), replacement=False, generator=rng)
+        hh, hw = H // 2, W // 2
+        for quad, (rows, cols) in enumerate(((slice(0, hh), slice(0, hw)), (slice(0, hh), slice(hw, W)),
+                                             (slice(hh, H), slice(0, hw)), (slice(hh, H), slice(hw, W)))):
+            sel = (q == quad).any(-1)
+            mask[sel, rows, cols] = False
+    return mask.reshape(n, -1)
 
 
 def shard_range(n, rank, world_size):
@@ -73,13 +91,27 @@ class MissingDataModule:
             if hp.dataset not in DATASET_DIMS:
                 raise NotImplementedError(f"unknown dataset {hp.dataset!r}")
             n = hp.synthetic_num_test or DATASET_TEST_SIZES[hp.dataset]
-            X = torch.randn(n, DATASET_DIMS[hp.dataset], generator=rng_dataset)
+            if hp.dataset in BINARY_DATASETS:
+                X = (torch.rand(n, DATASET_DIMS[hp.dataset], generator=rng_dataset) < 0.2).float()
+            else:
+                X = torch.randn(n, DATASET_DIMS[hp.dataset], generator=rng_dataset)
         else:
             raise FileNotFoundError(f"{path} not found (set data.synthetic: true for shape-faithful synthetic data)")
         self.test_data_core = AttrDict(data=X, data_min=X.min(0)[0].numpy(), data_max=X.max(0)[0].numpy())
-        if str(hp.missingness).split(".")[-1] != "uniform":
-            raise NotImplementedError(f"missingness {hp.missingness!r} (only 'uniform')")
-        M = uniform_missingness_mask(tuple(X.shape), hp.total_miss_test, rng)
+        kind = str(hp.missingness).split(".")[-1]
+        if kind == "uniform":
+            M = uniform_missingness_mask(tuple(X.shape), hp.total_miss_test, rng)
+        elif kind == "nan_miss":
+            # the data itself marks its missing entries with NaN (custom test points of the toy and
+            # MNIST-GMM configurations); the synthetic stand-in hides the lower half of the features
+            if hp.synthetic and not torch.isnan(X).any():
+                X = X.clone()
+                X[:, X.shape[1] // 2:] = float("nan")
+            M = ~torch.isnan(X)
+        elif kind == "quadrants":
+            M = quadrant_missingness_mask(X.shape[0], hp.img_dims, hp.total_miss_test, rng)
+        else:
+            raise NotImplementedError(f"missingness {hp.missingness!r} (only 'uniform', 'quadrants' and 'nan_miss')")
         I = torch.arange(X.shape[0], dtype=torch.int64)
         if hp.filter_fully_missing_test:
             keep = M.any(dim=1)

@@ -23,7 +23,7 @@ import torch
 import yaml
 
 from .data import MissingDataModule
-from .models import VAE, ResidualFCNetwork
+from .models import VAE, ResidualFCNetwork, ResNetDecoder, ResNetEncoder
 from .sampling import test_step_vae_sampling
 from .utils.hparams import AttrDict
 
@@ -57,9 +57,13 @@ def resolve_test_class(class_path):
 
 def build_network(spec):
     name = spec["class_path"].split(".")[-1]
+    a = dict(spec["init_args"])
+    if name == "ResNetEncoder":
+        return ResNetEncoder(**a)
+    if name == "ResNetDecoder":
+        return ResNetDecoder(**a)
     if name != "ResidualFCNetwork":
         raise NotImplementedError(f"network class {spec['class_path']!r} is not implemented")
-    a = dict(spec["init_args"])
     return ResidualFCNetwork(a.pop("input_dim"), a.pop("output_dim"), a.pop("num_residual_blocks"),
                              a.pop("residual_block_dim"), **a)
 

@@ -38,6 +38,10 @@ extern "C" {
 #define CS_DIST_NORMAL 0          /* scale = softplus(raw)            */
 #define CS_DIST_NORMAL_WITH_EPS 1 /* scale = softplus(raw) + 1e-8     */
 #define CS_DIST_BERN 2            /* logits                           */
+#define CS_DIST_BETA 3            /* latent only: (alpha, beta) = softplus(raw halves); vae.py:239-243 */
+/* prior over the latents (VAE.get_prior, vae.py:158-164) */
+#define CS_PRIOR_STD_NORMAL 0
+#define CS_PRIOR_UNIFORM 1        /* Uniform(0, 1 + 1e-8): use_uniform_prior (toy configuration) */
 
 /* importance weighting (vae_imputation.py:615-640) */
 #define CS_W_DMIS 0
@@ -123,6 +127,7 @@ typedef struct {
   int32_t cluster_size; /* glr / dmis_within_groups */
   float weight_alpha;   /* resampling uses alpha*log_w (polynomial transform,
                            test_step_vae_sampling.py:2059-2061); 1 = none */
+  int32_t prior;        /* CS_PRIOR_* */
 } cs_lair_cfg;
 
 typedef struct {

@@ -99,6 +99,8 @@ def split_loc_scale(params, dist):
     d = params.shape[-1] // 2
     loc, raw = params[..., :d], params[..., d:]
     scale = F.softplus(raw)
+    if dist == "beta":  # (alpha, beta) = softplus of both halves (vae.py:239-243)
+        return F.softplus(loc), scale
     if dist == "normal_with_eps":
         scale = scale + EPSILON
     elif dist != "normal":
@@ -110,6 +112,29 @@ def normal_log_prob(x, loc, scale):
     """torch.distributions.Normal.log_prob: -(x-loc)^2/(2 var) - log(scale) - log(sqrt(2 pi))."""
     var = scale ** 2
     return -((x - loc) ** 2) / (2 * var) - scale.log() - LOG_SQRT_2PI
+
+
+def beta_log_prob(z, alpha, beta):
+    """torch.distributions.Beta(alpha, beta).log_prob(z): Dirichlet.log_prob of (z, 1 - z) with
+    concentration (alpha, beta): xlogy(c - 1, v).sum + lgamma(c.sum) - lgamma(c).sum."""
+    alpha, beta = torch.broadcast_tensors(alpha, beta)
+    conc = torch.stack([alpha, beta], -1)
+    v = torch.stack([z, 1.0 - z], -1)
+    return torch.xlogy(conc - 1.0, v).sum(-1) + torch.lgamma(conc.sum(-1)) - torch.lgamma(conc).sum(-1)
+
+
+def latent_log_prob(z, p1, p2, dist):
+    """log q(z) per latent dimension: Normal(loc=p1, scale=p2) or Beta(p1, p2)."""
+    return beta_log_prob(z, p1, p2) if dist == "beta" else normal_log_prob(z, p1, p2)
+
+
+def uniform_prior_log_prob(z):
+    """Uniform(0., 1. + 1e-8).log_prob(z) with float32 bounds (vae.py:160): the upper bound rounds
+    to 1.0; log(1[low <= z] * 1[high > z]) - log(high - low)."""
+    low, high = torch.tensor(0.), torch.tensor(1. + 1e-8)
+    lb = low.le(z).type_as(low)
+    ub = high.gt(z).type_as(low)
+    return torch.log(lb.mul(ub)) - torch.log(high - low)
 
 
 def std_normal_log_prob(z):
@@ -152,6 +177,8 @@ def replenish_params(B, R, Zd, dist):
     (vae_imputation.py:563-577): loc 0, raw scale softplus^-1(1 [- 1e-8])."""
     means = torch.zeros(B, R, Zd)
     scales = torch.ones(B, R, Zd)
+    if dist == "beta":  # Beta(1, 1) = the uniform prior (:578-585)
+        return torch.cat([softplus_inverse(scales), softplus_inverse(scales)], dim=-1)
     if dist == "normal":
         raw = softplus_inverse(scales)
     elif dist == "normal_with_eps":
@@ -202,21 +229,21 @@ def systematic_indices(log_weights, U, num_dependent_samples):
 # --------------------------------------------------------------------------------------
 # importance weights
 # --------------------------------------------------------------------------------------
-def dmis_mixture_logprob(Z, q_loc, q_scale):
+def dmis_mixture_logprob(Z, q_loc, q_scale, latent_dist="normal"):
     """log of the deterministic-mixture proposal density at every proposal
     (weights.py:69-85).  Z[I,B,K,Zd], q_loc/q_scale[B,K,Zd] -> [I,B,K]:
     logsumexp_j sum_d log N(Z[i,b,k]; loc[b,j], scale[b,j]) - log K."""
     K = Z.shape[2]
     # comp[j,i,b,k] = sum_d log N(Z[i,b,k,d]; loc[b,j,d], scale[b,j,d])
     Zs = Z.unsqueeze(0).transpose(0, -2)  # [K(k),I,B,1,Zd]  (value k sits on axis 0)
-    lp = normal_log_prob(Zs, q_loc, q_scale)  # broadcast -> [K(k),I,B,K(j),Zd]
+    lp = latent_log_prob(Zs, q_loc, q_scale, latent_dist)  # broadcast -> [K(k),I,B,K(j),Zd]
     lp = lp.sum(-1)
     lp = torch.logsumexp(lp, dim=-1, keepdim=True)
     lp = lp - torch.log(torch.tensor(K))
     return lp.transpose(0, -1).squeeze(0)  # [I,B,K]
 
 
-def grouped_dmis_mixture_logprob(Z, q_loc, q_scale, cluster_size):
+def grouped_dmis_mixture_logprob(Z, q_loc, q_scale, cluster_size, latent_dist="normal"):
     """Mixture restricted to the proposal's own group (vae_imputation.py:407-434, no
     padding).  Layout '(c k)': member j belongs to group j mod (K/c); a group has c members."""
     I, B, K, Zd = Z.shape
@@ -226,23 +253,24 @@ def grouped_dmis_mixture_logprob(Z, q_loc, q_scale, cluster_size):
     loc = q_loc.reshape(B, c, G, Zd).permute(0, 2, 1, 3)          # b g c d
     scale = q_scale.reshape(B, c, G, Zd).permute(0, 2, 1, 3)
     Zs = Zg.unsqueeze(0).transpose(0, -2)                        # [c(val),I,B,G,1,Zd]
-    lp = normal_log_prob(Zs, loc, scale).sum(-1)                  # [c(val),I,B,G,c(comp)]
+    lp = latent_log_prob(Zs, loc, scale, latent_dist).sum(-1)     # [c(val),I,B,G,c(comp)]
     lp = torch.logsumexp(lp, dim=-1, keepdim=True)
     lp = lp - torch.log(torch.tensor(c))
     lp = lp.transpose(0, -1).squeeze(0)                           # [I,B,G,c]
     return lp.permute(0, 1, 3, 2).reshape(I, B, K)                # i b (c g)
 
 
-def lair_log_weights(X, M, Z, q_loc, q_scale, gen_params, gen_dist, weighting, cluster_size=None):
+def lair_log_weights(X, M, Z, q_loc, q_scale, gen_params, gen_dist, weighting, cluster_size=None,
+                     latent_dist="normal", prior="std_normal"):
     """log w = sum_d M log p(x_d|z) + sum log p(z) - log q_mix(z)  (weights.py:46-57)."""
     gl = (gen_log_prob(X, gen_params, gen_dist) * M).sum(-1)
-    pl = std_normal_log_prob(Z).sum(-1)
+    pl = (uniform_prior_log_prob(Z) if prior == "uniform" else std_normal_log_prob(Z)).sum(-1)
     if weighting == "dmis":
-        ql = dmis_mixture_logprob(Z, q_loc, q_scale)
+        ql = dmis_mixture_logprob(Z, q_loc, q_scale, latent_dist)
     elif weighting == "dmis_within_groups":
-        ql = grouped_dmis_mixture_logprob(Z, q_loc, q_scale, cluster_size)
+        ql = grouped_dmis_mixture_logprob(Z, q_loc, q_scale, cluster_size, latent_dist)
     elif weighting == "smis":
-        ql = normal_log_prob(Z, q_loc, q_scale).sum(-1)
+        ql = latent_log_prob(Z, q_loc, q_scale, latent_dist).sum(-1)
     else:
         raise NotImplementedError(weighting)
     return gl + pl - ql, gl, pl, ql
@@ -308,8 +336,9 @@ def lair_iteration(enc, dec, X, M, draws, *, num_imp_samples=1, weighting="dmis"
                    glr_cluster_size=None, num_prior_replenish_proposals=0,
                    latent_dist="normal_with_eps", gen_dist="normal_with_eps",
                    return_resampled_latents=False, weight_alpha=None,
-                   encoder=None, decoder=None):
-    """One LAIR step (vae_imputation.py:484-726) with injected draws.
+                   encoder=None, decoder=None, prior="std_normal"):
+    """One LAIR step (vae_imputation.py:484-726) with injected draws.  For latent_dist='beta'
+    'eps_z' holds the Beta samples themselves (torch draws them by rejection sampling).
 
     X[B,K,D] float32, M[B,1,D] bool.  draws: 'eps_z'[I,B,K',Zd], 'u_res' (float64
     [B,K'] for gr / [B*G,c] for glr multinomial; float32 [B,1] / [B,G,1] systematic),
@@ -332,10 +361,16 @@ def lair_iteration(enc, dec, X, M, draws, *, num_imp_samples=1, weighting="dmis"
         Xp = torch.cat([X, X[:, :1].expand(B, R, D)], dim=1)
     q_loc, q_scale = split_loc_scale(var_params, latent_dist)
     Kp = K + R
-    Z = q_loc + q_scale * draws["eps_z"]                      # [I,B,K',Zd]
+    if latent_dist == "beta":
+        # Beta.sample() returns a stride-2 view into the Dirichlet sample (x, 1-x); torch's CPU linear
+        # layer rounds differently (last bit) on that layout than on a contiguous tensor, so the
+        # injected samples are given the same layout
+        Z = torch.stack([draws["eps_z"], 1.0 - draws["eps_z"]], -1).select(-1, 0)   # [I,B,K',Zd]
+    else:
+        Z = q_loc + q_scale * draws["eps_z"]                  # [I,B,K',Zd]
     gen_params = decoder(Z)                                   # [I,B,K',P]
     log_w, gl, pl, ql = lair_log_weights(Xp, Mf, Z, q_loc, q_scale, gen_params, gen_dist,
-                                         weighting, glr_cluster_size)
+                                         weighting, glr_cluster_size, latent_dist, prior)
     t_log_w = log_w if weight_alpha is None else log_w * weight_alpha
 
     def resample(u):
@@ -394,13 +429,14 @@ def pseudo_gibbs_iteration(enc, dec, X, M, draws, *, latent_dist="normal_with_ep
     return X * M + X_m * (~M), Z
 
 
-def vae_samples_imputation(dec, X, M, draws, *, gen_dist="normal_with_eps", decoder=None):
+def vae_samples_imputation(dec, X, M, draws, *, gen_dist="normal_with_eps", decoder=None, prior="std_normal"):
     """Initial imputation from unconditional model samples
     (test_step_vae_sampling.py:279-287 with vae.py:166-178).  draws: 'z'[B*K,Zd] standard
     normal, 'eps_x'[B*K,D]."""
     decoder = decoder or (lambda z: resfc_forward(dec, z))
     B, K, D = X.shape
-    X_imp = gen_sample(decoder(draws["z"]), gen_dist, draws["eps_x"]).reshape(B, K, D)
+    z = draws["z"] * (1. + 1e-8) if prior == "uniform" else draws["z"]  # 'z' = torch.rand under the uniform prior
+    X_imp = gen_sample(decoder(z), gen_dist, draws["eps_x"]).reshape(B, K, D)
     Xc = X.clone()
     Xc[(~M).expand(B, K, D)] = 0.0
     return Xc * M + X_imp * (~M)

@@ -39,6 +39,10 @@ class TapeSource:
     def uniform(self, *shape):
         return self._take(("rand", "rand_like", "bernoulli"), shape)
 
+    def beta(self, *shape):
+        """Samples of a Beta posterior as torch's Dirichlet sampler returned them."""
+        return self._take(("beta",), shape)
+
     def uniform64(self, *shape):
         return self._take(("multinomial",), shape)
 
@@ -107,17 +111,17 @@ class SeededSource:
         return int(torch.randint(0, int(high), (1,), generator=self.g)[0])
 
 
-def initial_imputation(dec, X, M, src, gen_dist="normal_with_eps"):
+def initial_imputation(dec, X, M, src, gen_dist="normal_with_eps", prior="std_normal"):
     B, K, D = X.shape
     Zd = O.net_input_dim(dec)
-    draws = {"z": src.normal(B * K, Zd),
+    draws = {"z": src.uniform(B * K, Zd) if prior == "uniform" else src.normal(B * K, Zd),
              "eps_x": src.uniform(B * K, D) if gen_dist == "bern" else src.normal(B * K, D)}
-    return O.vae_samples_imputation(dec, X, M, draws, gen_dist=gen_dist)
+    return O.vae_samples_imputation(dec, X, M, draws, gen_dist=gen_dist, prior=prior)
 
 
-def _lair_draws(src, I, B, K, R, D, Zd, *, scheme, method, cluster, gen_dist, second):
+def _lair_draws(src, I, B, K, R, D, Zd, *, scheme, method, cluster, gen_dist, second, latent_dist="normal"):
     Kp = K + R
-    d = {"eps_z": src.normal(I, B, Kp, Zd)}
+    d = {"eps_z": src.beta(I, B, Kp, Zd) if latent_dist == "beta" else src.normal(I, B, Kp, Zd)}
     G = Kp // cluster if scheme == "glr" else 1
 
     def res():
@@ -136,7 +140,7 @@ def lair_sampler(enc, dec, X, M, src, *, num_iterations, num_imp_samples=1, weig
                  resampling_scheme="gr", resampling_method="multinomial", glr_cluster_size=None,
                  num_prior_replenish_proposals=0, prior_replenish_iteration_frequency=1, store_latents=False,
                  clip_imputations=False, weight_transform=None, latent_dist="normal_with_eps",
-                 gen_dist="normal_with_eps", collect_proposals=False):
+                 gen_dist="normal_with_eps", collect_proposals=False, prior="std_normal"):
     """Generator over LAIR iterations; yields the dict the reference yields plus, when
     ``collect_proposals``, 'Z_prop' and 'log_weights' for the final resampling."""
     B, K, D = X.shape
@@ -152,8 +156,8 @@ def lair_sampler(enc, dec, X, M, src, *, num_iterations, num_imp_samples=1, weig
             alpha = min((t + 10) / num_iterations, 1)
         draws = _lair_draws(src, num_imp_samples, B, K, R, D, Zd, scheme=resampling_scheme,
                             method=resampling_method, cluster=glr_cluster_size, gen_dist=gen_dist,
-                            second=store_latents)
-        o = O.lair_iteration(enc, dec, X, M, draws, num_imp_samples=num_imp_samples, weighting=weighting_scheme,
+                            second=store_latents, latent_dist=latent_dist)
+        o = O.lair_iteration(enc, dec, X, M, draws, num_imp_samples=num_imp_samples, weighting=weighting_scheme, prior=prior,
                              resampling_scheme=resampling_scheme, resampling_method=resampling_method,
                              glr_cluster_size=glr_cluster_size, num_prior_replenish_proposals=R,
                              latent_dist=latent_dist, gen_dist=gen_dist, return_resampled_latents=store_latents,

@@ -151,6 +151,9 @@ class DrawTape:
       * ``rand`` / ``rand_like``  the uniforms
       * ``bernoulli``    float32 uniforms u; result is ``u < p``
       * ``randint``      the integers drawn
+      * ``beta``         the samples of a Beta distribution as torch's Dirichlet sampler returned
+                         them (rejection sampling inside ATen: the samples, not the uniforms, are
+                         what can be replayed)
     """
 
     def __init__(self, seed=0):
@@ -165,7 +168,12 @@ class DrawTape:
         tape = self
         orig = dict(normal=torch.normal, randn=torch.randn, multinomial=torch.multinomial,
                     rand=torch.rand, rand_like=torch.rand_like, bernoulli=torch.bernoulli,
-                    randint=torch.randint)
+                    randint=torch.randint, dirichlet=torch._sample_dirichlet)
+
+        def sample_dirichlet(concentration, generator=None):
+            out = orig["dirichlet"](concentration, generator=tape.gen)
+            tape._rec("beta", out[..., 0])  # Beta.rsample = Dirichlet([a, b]).rsample().select(-1, 0)
+            return out
 
         def normal(mean, std, *a, **k):
             if not torch.is_tensor(mean):
@@ -217,12 +225,14 @@ class DrawTape:
 
         torch.normal, torch.randn, torch.multinomial = normal, randn, multinomial
         torch.rand, torch.rand_like, torch.bernoulli, torch.randint = rand, rand_like, bernoulli, randint
+        torch._sample_dirichlet = sample_dirichlet
         try:
             yield self
         finally:
             torch.normal, torch.randn, torch.multinomial = orig["normal"], orig["randn"], orig["multinomial"]
             torch.rand, torch.rand_like, torch.bernoulli = orig["rand"], orig["rand_like"], orig["bernoulli"]
             torch.randint = orig["randint"]
+            torch._sample_dirichlet = orig["dirichlet"]
 
 
 def multinomial_from_uniforms(probs, u):

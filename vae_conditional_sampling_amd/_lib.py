@@ -12,7 +12,8 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcsvae.so")
 
-CS_DIST = {"normal": 0, "normal_with_eps": 1, "bern": 2}
+CS_DIST = {"normal": 0, "normal_with_eps": 1, "bern": 2, "beta": 3}
+CS_PRIOR = {"std_normal": 0, "uniform": 1}
 CS_WEIGHTING = {"dmis": 0, "dmis_within_groups": 1, "smis": 2}
 CS_SCHEME = {"gr": 0, "glr": 1}
 CS_METHOD = {"multinomial": 0, "systematic": 1}
@@ -50,7 +51,8 @@ class cs_lair_cfg(C.Structure):
     _fields_ = [("B", C.c_int32), ("K", C.c_int32), ("R", C.c_int32), ("I", C.c_int32),
                 ("D", C.c_int32), ("Zd", C.c_int32), ("latent_dist", C.c_int32),
                 ("gen_dist", C.c_int32), ("weighting", C.c_int32), ("scheme", C.c_int32),
-                ("method", C.c_int32), ("cluster_size", C.c_int32), ("weight_alpha", C.c_float)]
+                ("method", C.c_int32), ("cluster_size", C.c_int32), ("weight_alpha", C.c_float),
+                ("prior", C.c_int32)]
 
 
 _LAIR_BUF_FIELDS = ["X", "M", "eps_z", "u_res", "u_res2", "u_sys", "u_sys2", "eps_x", "q", "Z", "gen",

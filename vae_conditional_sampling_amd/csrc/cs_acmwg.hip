@@ -214,7 +214,7 @@ extern "C" int cs_acmwg_init_state(const cs_mlp_t* enc, const cs_mlp_t* dec, con
   e.net = enc->dev; e.mode = CS_MLP_ENC; e.rows = (int64_t)c->B * c->K;
   e.in = b->X; e.in_stride = c->D; e.q = b->q;
   fill_mlp_common(e, c);
-  e.latent_eps = c->latent_dist == CS_DIST_NORMAL_WITH_EPS;
+  e.latent_dist = c->latent_dist;
   if (int rc = cs_mlp_launch(e, (hipStream_t)stream)) return rc;
   CsMlpArgs d;
   std::memset(&d, 0, sizeof(d));
@@ -254,7 +254,7 @@ extern "C" int cs_acmwg_step(const cs_mlp_t* enc, const cs_mlp_t* dec, const cs_
   e.net = enc->dev; e.mode = CS_MLP_ENC; e.rows = chains;
   e.in = b->ring; e.in_off = b->in_off; e.q = b->q;
   fill_mlp_common(e, c);
-  e.latent_eps = c->latent_dist == CS_DIST_NORMAL_WITH_EPS;
+  e.latent_dist = c->latent_dist;
   if (int rc = cs_mlp_launch(e, st)) return rc;
   CsMlpArgs d;
   std::memset(&d, 0, sizeof(d));

@@ -117,6 +117,39 @@ __device__ inline double cs_uniform64_elem(const CsPhilox& p, uint32_t stream, i
   return (e & 1u) ? cs_u01d(x[2], x[3]) : cs_u01d(x[0], x[1]);
 }
 
+// Gamma(shape, 1) by Marsaglia-Tsang squeeze-free rejection; one Philox block per attempt
+// (normal from words 0-1, acceptance uniform from word 2, small-shape boost uniform from word 3).
+// Attempts are bounded: after 32 rejections (probability < 1e-40) the mode-like value d is taken.
+__device__ inline float cs_gamma_sample(const CsPhilox& p, uint32_t stream, int64_t row, uint32_t blk0, float shape) {
+  const float a = shape < 1.0f ? shape + 1.0f : shape;
+  const float d = a - 1.0f / 3.0f, c = 1.0f / sqrtf(9.0f * d);
+  float g = d, boost = 1.0f;
+  for (uint32_t t = 0; t < 32; ++t) {
+    uint32_t x[4];
+    cs_philox_block(p, stream, row, blk0 + t, x);
+    const f32x4 n = cs_normal4(x);
+    if (t == 0 && shape < 1.0f) boost = powf(cs_u01f(x[3]), 1.0f / shape);
+    const float v1 = 1.0f + c * n.x;
+    if (v1 <= 0.0f) continue;
+    const float v = v1 * v1 * v1;
+    if (logf(cs_u01f(x[2])) < 0.5f * n.x * n.x + d - d * v + d * logf(v)) {
+      g = d * v;
+      break;
+    }
+  }
+  return g * boost;
+}
+// Beta(alpha, beta) = Ga / (Ga + Gb), clamped to the open unit interval as torch's Dirichlet
+// sampler does ([FLT_MIN, 1 - 2^-24]).  Element e of (stream,row) owns blocks [64e, 64e+64).
+__device__ inline float cs_beta_sample(const CsPhilox& p, uint32_t stream, int64_t row, uint32_t e, float alpha, float beta) {
+  const float ga = cs_gamma_sample(p, stream, row, 64u * e, alpha);
+  const float gb = cs_gamma_sample(p, stream, row, 64u * e + 32u, beta);
+  const float z = ga / (ga + gb);
+  return fminf(fmaxf(z, 1.17549435e-38f), 0.99999994f);
+}
+// torch.xlogy: 0 where x == 0, else x * log(y)
+__device__ inline float cs_xlogy(float x, float y) { return x == 0.0f ? 0.0f : x * logf(y); }
+
 // exp / log / reciprocal through the hardware transcendental instructions (v_exp_f32 = 2^x,
 // v_log_f32 = log2, v_rcp_f32; each accurate to 1 ulp).  The library versions cost 50-150
 // instructions apiece, which the epilogues of the fused kernels pay per output element; these

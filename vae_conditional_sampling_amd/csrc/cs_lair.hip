@@ -66,9 +66,17 @@ __global__ void __launch_bounds__(64) cs_lair_resample_kernel(const CsResampleAr
     for (int t = lane; t < ne * Kp * Zd; t += 64) {
       const int ej = t / Zd, d = t - ej * Zd;  // ej = e*Kp + j
       const float loc = qb[ej * 2 * Zd + d], sc = qb[ej * 2 * Zd + Zd + d];
-      l_loc[t] = loc;
-      l_2var[t] = 1.0f / (2.0f * (sc * sc));
-      l_logs[t] = logf(sc);
+      if (a.cfg.latent_dist == CS_DIST_BETA) {
+        // (loc, sc) = (alpha, beta): stage alpha-1, beta-1 and the log-normaliser of
+        // torch's Dirichlet.log_prob, lgamma(alpha+beta) - (lgamma(alpha) + lgamma(beta))
+        l_loc[t] = loc - 1.0f;
+        l_2var[t] = sc - 1.0f;
+        l_logs[t] = lgammaf(loc + sc) - (lgammaf(loc) + lgammaf(sc));
+      } else {
+        l_loc[t] = loc;
+        l_2var[t] = 1.0f / (2.0f * (sc * sc));
+        l_logs[t] = logf(sc);
+      }
     }
     for (int t = lane; t < ne * S * Zd; t += 64) {
       const int es = t / Zd, d = t - es * Zd;
@@ -118,38 +126,45 @@ __global__ void __launch_bounds__(64) cs_lair_resample_kernel(const CsResampleAr
     const float* qloc = l_loc + e_l * Kp * Zd;
     const float* q2v = l_2var + e_l * Kp * Zd;
     const float* qls = l_logs + e_l * Kp * Zd;
+    const bool beta = a.cfg.latent_dist == CS_DIST_BETA;
     float pl = 0.0f;
-    for (int d = 0; d < Zd; ++d) pl += cs_stdnormal_logpdf(z[d]);
-    // mixture components of this proposal: j = gm + mixG*cc, cc < mixc
-    const int gm = kp_s % a.mixG;
-    float ql;
-    if (a.cfg.weighting == CS_W_SMIS) {
-      float cj = 0.0f;
-      for (int d = 0; d < Zd; ++d) {
-        const float df = z[d] - qloc[kp_s * Zd + d];
-        cj += -(df * df) * q2v[kp_s * Zd + d] - qls[kp_s * Zd + d] - CS_LOG_SQRT_2PI;
-      }
-      ql = cj;
+    if (a.cfg.prior == CS_PRIOR_UNIFORM) {
+      // Uniform(0, 1 + 1e-8).log_prob (the upper bound is 1 in float32): log(1[0 <= z < 1]) - log(1)
+      for (int d = 0; d < Zd; ++d) pl += (z[d] >= 0.0f && z[d] < 1.0f) ? 0.0f : -INFINITY;
     } else {
-      float m = -INFINITY;
-      for (int cc = 0; cc < a.mixc; ++cc) {
-        const int j = gm + a.mixG * cc;
-        float cj = 0.0f;
+      for (int d = 0; d < Zd; ++d) pl += cs_stdnormal_logpdf(z[d]);
+    }
+    // log-density of component j at this proposal, summed over the latent dimensions
+    auto comp = [&](int j) {
+      float cj = 0.0f;
+      if (beta) {
+        for (int d = 0; d < Zd; ++d)
+          cj += (cs_xlogy(qloc[j * Zd + d], z[d]) + cs_xlogy(q2v[j * Zd + d], 1.0f - z[d])) + qls[j * Zd + d];
+      } else {
         for (int d = 0; d < Zd; ++d) {
           const float df = z[d] - qloc[j * Zd + d];
           cj += -(df * df) * q2v[j * Zd + d] - qls[j * Zd + d] - CS_LOG_SQRT_2PI;
         }
+      }
+      return cj;
+    };
+    // mixture components of this proposal: j = gm + mixG*cc, cc < mixc
+    const int gm = kp_s % a.mixG;
+    float ql;
+    if (a.cfg.weighting == CS_W_SMIS) {
+      ql = comp(kp_s);
+    } else {
+      float m = -INFINITY;
+      for (int cc = 0; cc < a.mixc; ++cc) {
+        const int j = gm + a.mixG * cc;
+        const float cj = comp(j);
         m = fmaxf(m, cj);
       }
       if (!(fabsf(m) < INFINITY)) m = 0.0f;
       float sum = 0.0f;
       for (int cc = 0; cc < a.mixc; ++cc) {
         const int j = gm + a.mixG * cc;
-        float cj = 0.0f;
-        for (int d = 0; d < Zd; ++d) {
-          const float df = z[d] - qloc[j * Zd + d];
-          cj += -(df * df) * q2v[j * Zd + d] - qls[j * Zd + d] - CS_LOG_SQRT_2PI;
-        }
+        const float cj = comp(j);
         sum += expf(cj - m);
       }
       ql = logf(sum) + m - logf((float)a.mixc);
@@ -314,9 +329,11 @@ __global__ void __launch_bounds__(64) cs_lair_resample_kernel(const CsResampleAr
 static int check_cfg(const cs_lair_cfg* c, const cs_lair_bufs* b) {
   CS_REQUIRE(c && b, "null argument");
   CS_REQUIRE(c->B >= 0 && c->K >= 1 && c->R >= 0 && c->I >= 1 && c->D >= 1 && c->Zd >= 1, "bad sizes");
-  CS_REQUIRE(c->latent_dist == CS_DIST_NORMAL || c->latent_dist == CS_DIST_NORMAL_WITH_EPS,
-             "latent distribution must be normal / normal_with_eps");
+  CS_REQUIRE(c->latent_dist == CS_DIST_NORMAL || c->latent_dist == CS_DIST_NORMAL_WITH_EPS ||
+                 c->latent_dist == CS_DIST_BETA,
+             "latent distribution must be normal / normal_with_eps / beta");
   CS_REQUIRE(c->gen_dist >= CS_DIST_NORMAL && c->gen_dist <= CS_DIST_BERN, "bad generator distribution");
+  CS_REQUIRE(c->prior == CS_PRIOR_STD_NORMAL || c->prior == CS_PRIOR_UNIFORM, "bad prior");
   return CS_OK;
 }
 
@@ -334,7 +351,7 @@ extern "C" int cs_lair_encode(const cs_mlp_t* enc, const cs_lair_cfg* c, const c
   a.in_stride = c->D;
   a.q = b->q;
   a.K = c->K; a.Kp = c->K + c->R; a.Zd = c->Zd; a.B = c->B; a.I = c->I; a.D = c->D;
-  a.latent_eps = c->latent_dist == CS_DIST_NORMAL_WITH_EPS;
+  a.latent_dist = c->latent_dist;
   return cs_mlp_launch(a, (hipStream_t)stream);
 }
 
@@ -354,6 +371,7 @@ extern "C" int cs_lair_decode(const cs_mlp_t* dec, const cs_lair_cfg* c, const c
   a.rows = (int64_t)c->I * c->B * a.Kp;
   a.q = b->q;
   a.gen_dist = c->gen_dist;
+  a.latent_dist = c->latent_dist;
   a.eps_z = b->eps_z;
   a.rng = cs_make_philox(rng);
   a.Z = b->Z;

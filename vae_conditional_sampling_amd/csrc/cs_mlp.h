@@ -44,7 +44,7 @@ struct CsMlpArgs {
   // DEC: rows are (i,b,k'), k' < Kp
   float* q;
   int K, Kp, Zd, B, I, D;
-  int latent_eps;  // 1: scale += 1e-8
+  int latent_dist; // CS_DIST_* of the latent posterior (ENC epilogue, DEC proposal sampling)
   int gen_dist;    // CS_DIST_*
   // DEC prologue
   const float* eps_z;         // [rows,Zd] or nullptr -> Philox

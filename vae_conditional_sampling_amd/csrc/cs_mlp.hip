@@ -35,6 +35,12 @@ int cs_mlp_launch(const CsMlpArgs& a_in, hipStream_t stream) {
   a.dbg = g_trace;
   if (a.rows <= 0) return CS_OK;
   if (a.net.prog) return cs_prog_launch(a, stream);
+  if (a.mode == CS_MLP_DEC && a.in == nullptr && a.latent_dist == CS_DIST_BETA) {
+    // Beta proposals are drawn by a kernel of their own; the fused kernel then reads Z as its input
+    if (int rc = cs_dec_stage_launch(a, 0, a.rows, stream)) return rc;
+    a.in = a.Z;
+    a.in_stride = a.Zd;
+  }
   CS_REQUIRE(a.rows < ((int64_t)1 << 31) * 16, "too many rows");
   if (a.net.split == 2) CS_REQUIRE(a.net.nto == 2 * a.net.tph, "bad tile split");
   if (a.mode == CS_MLP_ENC) CS_REQUIRE(a.net.split == 2, "encoder output must be (loc | scale)");

@@ -27,3 +27,6 @@ struct CsProgram {
 // fused kernel).
 int cs_prog_launch(const CsMlpArgs& a, hipStream_t stream);
 void cs_prog_destroy(CsProgram* p);
+// Proposal sampling Z = sample(q) for rows [row0, row0+rows) of a DEC launch, as a kernel of its
+// own (the layer programs, and posterior families the fused kernel's prologue does not sample).
+int cs_dec_stage_launch(const CsMlpArgs& a, int64_t row0, int64_t rows, hipStream_t stream);

@@ -291,7 +291,9 @@ __global__ void __launch_bounds__(256) cs_gather_rows_kernel(const float* in, in
   out[idx] = in[(in_off ? in_off[row] : row * in_stride) + c];
 }
 
-// Z = loc + scale * eps (or the override row); one thread per 4 latent dimensions.
+// Z = loc + scale * eps (or the override row); one thread per 4 latent dimensions.  Beta
+// posteriors (toy configuration, vae.py:239-243): Z ~ Beta(alpha, beta) from the counter RNG, or
+// the injected sample itself (eps_z then holds the Beta draws).
 __global__ void __launch_bounds__(256) cs_dec_stage_kernel(const CsMlpArgs a, int64_t row0, int64_t rows) {
   const int Zd = a.Zd, nq = (Zd + 3) >> 2;
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -305,8 +307,9 @@ __global__ void __launch_bounds__(256) cs_dec_stage_kernel(const CsMlpArgs a, in
   const float* qr = a.q + (b * a.Kp + kp) * 2 * Zd;
   const bool ovr = a.z_override != nullptr && a.z_override[row] != 0;
   f32x4 e = {0.f, 0.f, 0.f, 0.f};
-  if (a.eps_z == nullptr && !ovr) {
-    const int64_t prow = (a.rng.row_offset + b) * ((int64_t)a.I * a.Kp) + i * a.Kp + kp;
+  const bool beta = a.latent_dist == CS_DIST_BETA;
+  const int64_t prow = (a.rng.row_offset + b) * ((int64_t)a.I * a.Kp) + i * a.Kp + kp;
+  if (a.eps_z == nullptr && !ovr && !beta) {
     uint32_t x[4];
     cs_philox_block(a.rng, CS_STREAM_Z, prow, (uint32_t)(c0 >> 2), x);
     e = cs_normal4(x);
@@ -317,6 +320,8 @@ __global__ void __launch_bounds__(256) cs_dec_stage_kernel(const CsMlpArgs a, in
     float z;
     if (ovr) {
       z = a.z_alt[row * Zd + c];
+    } else if (beta) {
+      z = a.eps_z ? a.eps_z[row * Zd + c] : cs_beta_sample(a.rng, CS_STREAM_Z, prow, (uint32_t)c, qr[c], qr[Zd + c]);
     } else {
       const float ev = a.eps_z ? a.eps_z[row * Zd + c] : e[r];
       z = qr[c] + qr[Zd + c] * ev;
@@ -337,13 +342,14 @@ __global__ void __launch_bounds__(256) cs_enc_finish_kernel(const CsMlpArgs a, c
   const int64_t b = row / a.K;
   const int64_t k = row - b * a.K;
   float* qr = a.q + (b * a.Kp + k) * 2 * Zd;
+  const bool beta = a.latent_dist == CS_DIST_BETA;
   float sc = cs_softplus(raw[r * 2 * Zd + Zd + z]);
-  if (a.latent_eps) sc += 1e-8f;
-  qr[z] = raw[r * 2 * Zd + z];
+  if (a.latent_dist == CS_DIST_NORMAL_WITH_EPS) sc += 1e-8f;
+  qr[z] = beta ? cs_softplus(raw[r * 2 * Zd + z]) : raw[r * 2 * Zd + z];
   qr[Zd + z] = sc;
-  if (k == 0 && a.Kp > a.K) {
+  if (k == 0 && a.Kp > a.K) {  // replenishing proposals: N(0, 1), or Beta(1, 1) = the uniform prior
     float* qp = a.q + (b * a.Kp + a.K) * 2 * Zd;
-    for (int t = z; t < (a.Kp - a.K) * 2 * Zd; t += Zd) qp[t] = ((t / Zd) & 1) ? 1.0f : 0.0f;
+    for (int t = z; t < (a.Kp - a.K) * 2 * Zd; t += Zd) qp[t] = (beta || ((t / Zd) & 1)) ? 1.0f : 0.0f;
   }
 }
 
@@ -435,6 +441,13 @@ bool mfma_eligible(const cs_layer_desc& d) {
 constexpr int64_t kWorkspaceBudgetBytes = (int64_t)6 << 30;
 
 }  // namespace
+
+int cs_dec_stage_launch(const CsMlpArgs& a, int64_t row0, int64_t rows, hipStream_t stream) {
+  const int64_t n = rows * ((a.Zd + 3) / 4);
+  hipLaunchKernelGGL(cs_dec_stage_kernel, dim3(blocks_for(n)), dim3(256), 0, stream, a, row0, rows);
+  CS_HIP(hipGetLastError());
+  return CS_OK;
+}
 
 void cs_prog_destroy(CsProgram* p) {
   if (!p) return;
@@ -570,8 +583,7 @@ int cs_prog_launch(const CsMlpArgs& a, hipStream_t stream) {
     for (int b = 0; b < CS_NET_NBUF; ++b) buf[b] = p->ws + prefix[b] * chunk;
     const float* input;
     if (a.mode == CS_MLP_DEC && a.in == nullptr) {
-      const int64_t n = rows * ((a.Zd + 3) / 4);
-      hipLaunchKernelGGL(cs_dec_stage_kernel, dim3(blocks_for(n)), dim3(256), 0, stream, a, row0, rows);
+      if (int rc = cs_dec_stage_launch(a, row0, rows, stream)) return rc;
       input = a.Z + row0 * a.Zd;
     } else if (a.in_off == nullptr && a.in_stride == p->in_dim) {
       input = a.in + row0 * p->in_dim;

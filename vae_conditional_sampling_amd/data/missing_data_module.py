@@ -24,10 +24,20 @@ import torch
 from ..utils.hparams import AttrDict
 
 DATASET_DIMS = {"uci_miniboone": 43, "uci_hepmass": 21, "uci_gas": 8, "uci_power": 6, "toy_grid2dmog4": 2,
-                "omniglot28x28_fbin": 784, "mnist_gmm": 196, "mnist_gmm_custtest0": 196}
+                "omniglot28x28_fbin": 784, "mnist_gmm": 196, "mnist_gmm_custtest0": 196,
+                "toy_grid2dmog_custtest0": 2}
 DATASET_TEST_SIZES = {"uci_miniboone": 3648, "uci_hepmass": 174987, "uci_gas": 105206, "uci_power": 204928,
-                      "toy_grid2dmog4": 14, "omniglot28x28_fbin": 8070, "mnist_gmm": 10, "mnist_gmm_custtest0": 10}
+                      "toy_grid2dmog4": 14, "omniglot28x28_fbin": 8070, "mnist_gmm": 10, "mnist_gmm_custtest0": 10,
+                      "toy_grid2dmog_custtest0": 14}
 BINARY_DATASETS = ("omniglot28x28_fbin",)  # synthetic stand-in: Bernoulli(0.2) pixels
+
+
+def toy_custom_test_points():
+    """The 14 fixed test points of the toy configuration, one coordinate observed at
+    -2, -1, -0.5, 0, 0.5, 1, 2 and the other missing (NaN) (irwg/data/toy.py:605-621)."""
+    v = torch.tensor([-2., -1., -.5, 0., .5, 1., 2.])
+    nan = torch.full_like(v, float("nan"))
+    return torch.cat([torch.stack([nan, v], 1), torch.stack([v, nan], 1)])
 
 
 def uniform_missingness_mask(shape, total_miss, rng):
@@ -87,6 +97,8 @@ class MissingDataModule:
         path = os.path.join(hp.data_root, hp.dataset, "test.npy")
         if os.path.exists(path):
             X = torch.from_numpy(np.load(path, allow_pickle=False).astype(np.float32))
+        elif hp.dataset == "toy_grid2dmog_custtest0":
+            X = toy_custom_test_points()  # defined in code by the reference too: no data file
         elif hp.synthetic:
             if hp.dataset not in DATASET_DIMS:
                 raise NotImplementedError(f"unknown dataset {hp.dataset!r}")
@@ -97,7 +109,8 @@ class MissingDataModule:
                 X = torch.randn(n, DATASET_DIMS[hp.dataset], generator=rng_dataset)
         else:
             raise FileNotFoundError(f"{path} not found (set data.synthetic: true for shape-faithful synthetic data)")
-        self.test_data_core = AttrDict(data=X, data_min=X.min(0)[0].numpy(), data_max=X.max(0)[0].numpy())
+        Xf = torch.nan_to_num(X, nan=0.0)
+        self.test_data_core = AttrDict(data=X, data_min=Xf.min(0)[0].numpy(), data_max=Xf.max(0)[0].numpy())
         kind = str(hp.missingness).split(".")[-1]
         if kind == "uniform":
             M = uniform_missingness_mask(tuple(X.shape), hp.total_miss_test, rng)

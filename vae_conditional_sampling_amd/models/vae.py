@@ -29,7 +29,7 @@ class DISTRIBUTION(Enum):
     beta_implrep = auto()
 
 
-_SUPPORTED_LATENT = (DISTRIBUTION.normal, DISTRIBUTION.normal_with_eps)
+_SUPPORTED_LATENT = (DISTRIBUTION.normal, DISTRIBUTION.normal_with_eps, DISTRIBUTION.beta)
 _SUPPORTED_GEN = (DISTRIBUTION.normal, DISTRIBUTION.normal_with_eps, DISTRIBUTION.bern)
 
 
@@ -77,13 +77,15 @@ class VAE(nn.Module):
         hp = self.hparams
         if hp.encoder_use_mis_mask:
             raise NotImplementedError("encoder_use_mis_mask=True is not implemented")
-        if hp.use_uniform_prior:
-            raise NotImplementedError("uniform prior is not implemented (standard normal prior only)")
         if hp.var_latent_distribution not in _SUPPORTED_LATENT:
             raise NotImplementedError(f"Method not implemented for {hp.var_latent_distribution = }")
         if hp.generator_distribution not in _SUPPORTED_GEN:
             raise NotImplementedError(f"Method not implemented for {hp.generator_distribution = }")
         return (_lib.CS_DIST[hp.var_latent_distribution.name], _lib.CS_DIST[hp.generator_distribution.name])
+
+    def engine_prior(self):
+        """Prior code of the C ABI (VAE.get_prior, vae.py:158-164)."""
+        return _lib.CS_PRIOR["uniform" if self.hparams.use_uniform_prior else "std_normal"]
 
     # ---- reference interface -----------------------------------------------------------
     def get_prior(self):
@@ -116,6 +118,10 @@ class VAE(nn.Module):
             return torch.distributions.Normal(loc=loc, scale=scale, validate_args=validate_args)
         if distribution is DISTRIBUTION.bern:
             return torch.distributions.Bernoulli(logits=params, validate_args=validate_args)
+        if distribution is DISTRIBUTION.beta:
+            a, b = self.split_params(params, 2)
+            return torch.distributions.Beta(concentration1=torch.nn.functional.softplus(a),
+                                            concentration0=torch.nn.functional.softplus(b), validate_args=validate_args)
         raise NotImplementedError(f"Method not implemented for {distribution = }")
 
     def sample(self, num_samples, rng=None, *, return_latents=False, draws=None):

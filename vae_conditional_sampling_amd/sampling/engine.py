@@ -65,7 +65,8 @@ def lair_cfg(model, ws, *, weighting, scheme, method, cluster_size, weight_alpha
     except KeyError:
         raise NotImplementedError(f"{weighting=}, {scheme=}, {method=}")
     return _lib.cs_lair_cfg(ws.B, ws.K, ws.R, ws.I, ws.D, ws.Zd, latent, gen, w, s, m,
-                            int(cluster_size or 0), float(1.0 if weight_alpha is None else weight_alpha))
+                            int(cluster_size or 0), float(1.0 if weight_alpha is None else weight_alpha),
+                            model.engine_prior())
 
 
 def lair_step(model, ws, X, M8, cfg, *, rng=None, draws=None, return_resampled_latents=False,
@@ -143,15 +144,21 @@ def rng_uniform64(rng, stream_id, rows, cols, device):
 
 
 def vae_sample(model, num_samples, *, rng=None, draws=None, return_latents=False):
-    """x ~ p(x|z), z ~ N(0,I) (irwg/models/vae.py:166-178)."""
+    """x ~ p(x|z), z ~ N(0,I) or z = u * (1 + 1e-8), u ~ U[0,1) under the uniform prior
+    (irwg/models/vae.py:166-178).  An injected 'z' holds the normals / the uniforms u."""
     draws = draws or {}
     dev = model.device
     rng = rng if rng is not None else _lib.make_rng(0)
     Zd = model.latent_dim
+    uniform = bool(model.hparams.use_uniform_prior)
     if draws.get("z") is not None:
         Z = draws["z"].to(dev, torch.float32).contiguous()
+    elif uniform:
+        Z = rng_uniform(rng, _lib.STREAM_INIT_Z, num_samples, Zd, dev)
     else:
         Z = rng_normal(rng, _lib.STREAM_INIT_Z, num_samples, Zd, dev)
+    if uniform:
+        Z = Z * (1. + 1e-8)
     gen = decode_params(model, Z)
     D = gen.shape[-1] // (1 if model.hparams.generator_distribution.name == "bern" else 2)
     X = torch.empty(num_samples, D, device=dev, dtype=torch.float32)

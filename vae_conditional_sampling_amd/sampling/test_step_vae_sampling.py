@@ -191,12 +191,19 @@ class TestVAESamplerBase(HyperparametersMixin):
         draws = None
         if src is not None:
             bern = self.model.hparams.generator_distribution.name == "bern"
-            draws = {"z": src.normal(B * K, self.model.latent_dim),
+            uni = bool(self.model.hparams.use_uniform_prior)  # VAE.sample draws torch.rand then
+            draws = {"z": (src.uniform if uni else src.normal)(B * K, self.model.latent_dim),
                      "eps_x": src.uniform(B * K, D) if bern else src.normal(B * K, D)}
         # rng rows are (example_offset + b)*K + k of a dedicated stream: independent of batching
         rng = _lib.make_rng(self.rng_seed, 0, self.example_offset * K)
-        Z = (draws["z"].to(X.device, torch.float32).contiguous() if draws is not None
-             else engine.rng_normal(rng, _lib.STREAM_INIT_Z, B * K, self.model.latent_dim, X.device))
+        if draws is not None:
+            Z = draws["z"].to(X.device, torch.float32).contiguous()
+        elif self.model.hparams.use_uniform_prior:
+            Z = engine.rng_uniform(rng, _lib.STREAM_INIT_Z, B * K, self.model.latent_dim, X.device)
+        else:
+            Z = engine.rng_normal(rng, _lib.STREAM_INIT_Z, B * K, self.model.latent_dim, X.device)
+        if self.model.hparams.use_uniform_prior:
+            Z = Z * (1. + 1e-8)  # vae.py:168
         gen = engine.decode_params(self.model, Z)
         Xn = X.clone().contiguous()
         rng_x = _lib.make_rng(self.rng_seed, 0, self.example_offset)
@@ -326,7 +333,9 @@ class TestVAELatentAdaptiveImportanceResampling(TestVAESamplerBase):
         hp = self.hparams
         I, Kp, Zd = hp.num_imp_samples, K + R, self.model.latent_dim
         bern = self.model.hparams.generator_distribution.name == "bern"
-        d = {"eps_z": src.normal(I, B, Kp, Zd)}
+        # a Beta posterior is sampled by torch's Dirichlet sampler: the tape holds the samples
+        beta = self.model.hparams.var_latent_distribution.name == "beta"
+        d = {"eps_z": src.beta(I, B, Kp, Zd) if beta else src.normal(I, B, Kp, Zd)}
         G = Kp // hp.glr_cluster_size if hp.resampling_scheme == 'glr' else 1
 
         def res():

@@ -240,6 +240,18 @@ int cs_history_set_available(int64_t* avail, const uint8_t* mask, int64_t chains
  * (test_step_vae_sampling.py:1655). */
 int cs_stdnormal_logprob_rows(const float* Z, int64_t rows, int32_t Zd, float* out, void* stream);
 
+/* Per-iteration imputation diagnostics (test_step_vae_sampling.py:431-445), on the device.
+ * rmse[b,k] = sqrt(sum_{d missing} (X[b,k,d] - X_true[b,d])^2 / max(#missing_b, 1))
+ * (imputation_rmse_metric, irwg/sampling/imputation_metrics.py:85-102); mae likewise with |.|
+ * (imputation_mae_metric, :133-143).  Either output may be NULL. */
+int cs_imputation_errors(const float* X, const float* X_true, const uint8_t* M, int64_t B, int32_t K, int32_t D,
+                         float* rmse, float* mae, void* stream);
+/* out[b,k] = 2-Wasserstein distance (squared) between the Gaussian posteriors q_imp[B,K,2,Zd] and
+ * q_true[B,1,2,Zd] given as (loc, scale): imputation_latent_wass (imputation_metrics.py:200-213)
+ * after the two encoder passes (cs_lair_encode). */
+int cs_latent_wasserstein(const float* q_imp, const float* q_true, int64_t B, int32_t K, int32_t Zd, float* out,
+                          void* stream);
+
 /* gen[rows,2,D] (mean, scale) or [rows,D] (Bernoulli logits) = generator parameterisation of
  * generator_network(Z[rows,Zd]) (vae.py:171-172,203-256). */
 int cs_decode_params(const cs_mlp_t* dec, const float* Z, int64_t rows, int32_t gen_dist, float* gen, void* stream);

@@ -244,10 +244,34 @@ def case_lair_sampler(ns, name, *, B, K, R, D, Zd, H, seed, T, n_final=None, fre
     print(f"[ok] {name}")
 
 
+def case_metrics(ns, name, *, B, K, D, Zd, H, seed):
+    """Per-iteration diagnostics (irwg/sampling/imputation_metrics.py:85-102,133-143,200-213)."""
+    import importlib
+    im = importlib.import_module("irwg.sampling.imputation_metrics")
+    enc = O.make_resfc_weights(D, 2 * Zd, 2, H, seed)
+    dec = O.make_resfc_weights(Zd, 2 * D, 1, H, seed + 1)
+    vae = ref_vae(ns, enc, dec)
+    X, M = make_inputs(B, K, D, seed + 2)
+    g = torch.Generator().manual_seed(seed + 3)
+    X_true = X[:, :1] * M + torch.randn(B, 1, D, generator=g) * (~M)
+    M[0] = True  # a fully observed example: the count of missing entries is replaced by 1
+    with torch.no_grad():
+        rmse, mae = im.imputation_rmse_metric(X, X_true, M), im.imputation_mae_metric(X, X_true, M)
+        wass = im.imputation_latent_wass(X, X_true, vae)
+        assert torch.equal(rmse, O.imputation_rmse_metric(X, X_true, M))
+        assert torch.equal(mae, O.imputation_mae_metric(X, X_true, M))
+        assert torch.equal(wass, O.imputation_latent_wass(enc, X, X_true))
+    fx = dict(flat_weights("enc", enc)); fx.update(flat_weights("dec", dec))
+    fx.update(X=X.numpy(), X_true=X_true.numpy(), M=M.numpy(), rmse=rmse.numpy(), mae=mae.numpy(), latent_wass=wass.numpy())
+    np.savez_compressed(os.path.join(GOLDEN, f"{name}.npz"), **fx)
+    print(f"[ok] {name}")
+
+
 def main():
     os.makedirs(GOLDEN, exist_ok=True)
     ns = load_reference()
     torch.manual_seed(0)
+    case_metrics(ns, "metrics_small", B=7, K=3, D=70, Zd=5, H=64, seed=31)
     case_lair(ns, "lair_gr_mult_small", B=6, K=4, R=1, I=1, D=11, Zd=5, H=64, nb_enc=2, nb_dec=1, seed=101)
     case_lair(ns, "lair_gr_mult_i2_lat", B=5, K=3, R=2, I=2, D=9, Zd=4, H=64, nb_enc=1, nb_dec=2, seed=202,
               resampled_latents=True)

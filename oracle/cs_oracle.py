@@ -442,6 +442,38 @@ def vae_samples_imputation(dec, X, M, draws, *, gen_dist="normal_with_eps", deco
     return Xc * M + X_imp * (~M)
 
 
+# --------------------------------------------------------------------------------------
+# per-iteration diagnostics (irwg/sampling/imputation_metrics.py)
+# --------------------------------------------------------------------------------------
+def imputation_rmse_metric(X_imp, X_true, M):
+    """imputation_metrics.py:85-102.  X_imp[B,K,D], X_true[B,1,D], M bool [B,1,D] -> [B,K]."""
+    M_not = ~M
+    se = (((X_imp - X_true) ** 2) * M_not).sum(-1)
+    count = M_not.sum(-1)
+    count[count == 0] = 1
+    return (se / count) ** 0.5
+
+
+def imputation_mae_metric(X_imp, X_true, M):
+    """imputation_metrics.py:133-143."""
+    M_not = ~M
+    ae = (torch.absolute(X_imp - X_true) * M_not).sum(-1)
+    count = M_not.sum(-1)
+    count[count == 0] = 1
+    return ae / count
+
+
+def imputation_latent_wass(enc, X_imp, X_true, latent_dist="normal_with_eps"):
+    """imputation_metrics.py:200-213: squared 2-Wasserstein distance between the Gaussian
+    posteriors of the imputed and the true datapoints."""
+    li, si = split_loc_scale(resfc_forward(enc, X_imp), latent_dist)
+    lt, st = split_loc_scale(resfc_forward(enc, X_true), latent_dist)
+    vi, vt = si ** 2, st ** 2
+    W = torch.sum((li - lt) ** 2, dim=-1)
+    W += torch.sum(vi + vt - 2 * (vi * vt) ** 0.5, dim=-1)
+    return W
+
+
 def final_resample(latent_proposals, log_weights, u, num_samples):
     """LAIR final resampling over all T*I*K' stored proposals
     (test_step_vae_sampling.py:1998-2009).  latent_proposals[T,I,B,K',Zd],

@@ -85,6 +85,17 @@ def test_yaml_driver_end_to_end_lair_and_acmwg(tmp_path):
     f1 = np.load(os.path.join(tester.out_dir, "irwg_imputations_after_final_resampling_1.npz"))
     assert f1["imputations"].shape == (1, 36, 6 * 5, 43)
     assert all(0 < e <= 5 for e in outs[0]["is_ess"])
+    # the configuration enables the RMSE / MAE / latent-Wasserstein diagnostics: [T, B, K] per batch
+    for name in ("rmse", "mae", "latent_wass"):
+        v = outs[0][f"imp_metric/{name}"]
+        assert v.shape == (6, 64, 4) and np.isfinite(v).all() and (v >= 0).all()
+    ms = np.load(os.path.join(tester.out_dir, "metrics_summary.npz"))
+    assert ms["rmse__mean__test"].shape == (6,) and ms["rmse__q0.5__test"].shape == (6,)
+    assert ms["is_ess__test"].shape == (6,)
+    # cross-check one entry of the RMSE against the stored imputations
+    imp, tx, mk = f0["imputations"][3], f0["true_X"], f0["masks"]
+    ref = np.sqrt((((imp - tx) ** 2) * ~mk).sum(-1) / np.maximum((~mk).sum(-1), 1))
+    assert np.allclose(outs[0]["imp_metric/rmse"][2], ref, rtol=1e-5, atol=1e-6)
 
     cfg = driver.load_config(os.path.join(ROOT, "configs/uci_miniboone/sampling_u50/acmwg_k5_005prior_irwg_warmup.yaml"),
                              common + ["test_class.init_args.num_pseudo_warmup_iterations=2",

@@ -40,7 +40,7 @@ def test_unsupported_options_raise_not_implemented():
     from vae_conditional_sampling_amd.sampling.test_step_vae_sampling import TestVAELatentAdaptiveImportanceResampling
     from vae_conditional_sampling_amd.sampling.vae_imputation import importance_resampling_gibbs_iteration
     kw = dict(BASE_KW)
-    kw["compute_rmse_metric"] = True
+    kw["compute_ssim_metric"] = True  # a diagnostic that is not implemented (RMSE, MAE, latent-Wasserstein are)
     s = TestVAELatentAdaptiveImportanceResampling(num_iterations=1, num_imp_samples=1, weighting_scheme="dmis",
                                                   resampling_scheme="gr", resampling_method="multinomial", **kw)
     with pytest.raises(NotImplementedError):

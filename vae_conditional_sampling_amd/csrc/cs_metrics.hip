@@ -1,0 +1,86 @@
+// Per-iteration imputation diagnostics of the sampling harness, computed on the device so that no
+// imputation leaves HBM during the sampler loop.
+//
+// Replaces imputation_rmse_metric (irwg/sampling/imputation_metrics.py:85-102),
+// imputation_mae_metric (:133-143) and the closed-form part of imputation_latent_wass (:200-213),
+// as called once per iteration from test_step (irwg/sampling/test_step_vae_sampling.py:431-445).
+#include "cs_common.h"
+
+namespace {
+
+// One wavefront per (example, chain): squared / absolute error over the missing entries divided by
+// their count (a count of 0 is replaced by 1, :92-93).
+__global__ void __launch_bounds__(256) cs_imputation_error_kernel(const float* X, const float* Xt, const uint8_t* M,
+                                                                  int64_t rows, int K, int D, float* rmse, float* mae) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int64_t b = row / K;
+  const float* x = X + row * D;
+  const float* t = Xt + b * D;
+  const uint8_t* m = M + b * D;
+  float se = 0.0f, ae = 0.0f, cnt = 0.0f;
+  for (int d = lane; d < D; d += 64) {
+    const float miss = m[d] ? 0.0f : 1.0f;
+    const float df = x[d] - t[d];
+    se += df * df * miss;  // (X_imp - X_true)**2 * ~M: a non-finite difference times 0 stays NaN, as in torch
+    ae += fabsf(df) * miss;
+    cnt += miss;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    se += __shfl_xor(se, o);
+    ae += __shfl_xor(ae, o);
+    cnt += __shfl_xor(cnt, o);
+  }
+  if (lane == 0) {
+    if (cnt == 0.0f) cnt = 1.0f;
+    if (rmse) rmse[row] = sqrtf(se / cnt);
+    if (mae) mae[row] = ae / cnt;
+  }
+}
+
+// W[b,k] = sum_z (mu_i - mu_t)^2 + sum_z (var_i + var_t - 2 sqrt(var_i var_t)) between the Gaussian
+// posteriors of the imputed and the true datapoint; q rows are (loc | scale).
+__global__ void __launch_bounds__(256) cs_latent_wass_kernel(const float* q_imp, const float* q_true, int64_t rows, int K,
+                                                             int Zd, float* out) {
+  const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (row >= rows) return;
+  const int64_t b = row / K;
+  const float* qi = q_imp + row * 2 * Zd;
+  const float* qt = q_true + b * 2 * Zd;
+  float w1 = 0.0f, w2 = 0.0f;
+  for (int z = 0; z < Zd; ++z) {
+    const float dm = qi[z] - qt[z];
+    w1 += dm * dm;
+    const float vi = qi[Zd + z] * qi[Zd + z], vt = qt[Zd + z] * qt[Zd + z];
+    w2 += vi + vt - 2.0f * sqrtf(vi * vt);
+  }
+  out[row] = w1 + w2;
+}
+
+}  // namespace
+
+extern "C" int cs_imputation_errors(const float* X, const float* X_true, const uint8_t* M, int64_t B, int32_t K, int32_t D,
+                                    float* rmse, float* mae, void* stream) {
+  CS_REQUIRE(X && X_true && M && (rmse || mae), "null argument");
+  CS_REQUIRE(B >= 0 && K >= 1 && D >= 1, "bad sizes");
+  const int64_t rows = B * K;
+  if (rows == 0) return CS_OK;
+  hipLaunchKernelGGL(cs_imputation_error_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, X,
+                     X_true, M, rows, K, D, rmse, mae);
+  CS_HIP(hipGetLastError());
+  return CS_OK;
+}
+
+extern "C" int cs_latent_wasserstein(const float* q_imp, const float* q_true, int64_t B, int32_t K, int32_t Zd, float* out,
+                                     void* stream) {
+  CS_REQUIRE(q_imp && q_true && out, "null argument");
+  CS_REQUIRE(B >= 0 && K >= 1 && Zd >= 1, "bad sizes");
+  const int64_t rows = B * K;
+  if (rows == 0) return CS_OK;
+  hipLaunchKernelGGL(cs_latent_wass_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream, q_imp,
+                     q_true, rows, K, Zd, out);
+  CS_HIP(hipGetLastError());
+  return CS_OK;
+}

@@ -24,13 +24,14 @@ import torch
 
 from .. import _lib
 from ..utils.hparams import HyperparametersMixin
-from . import engine
+from . import engine, imputation_metrics
 from .utils import ImputationHistoryQueue_with_restrictedavailability
 from .vae_imputation import importance_resampling_gibbs_iteration, pseudo_gibbs_iteration
 
+# diagnostics of the reference's harness that are NOT implemented here (the point-wise RMSE, MAE and
+# latent-Wasserstein metrics are: sampling/imputation_metrics.py)
 _DIAGNOSTIC_FLAGS = ("compute_f1_metric", "compute_inv_f1_metric", "compute_bin_accuracy_metric",
-                     "compute_rmse_metric", "compute_ssim_metric", "compute_latent_wass_metric",
-                     "compute_mae_metric", "estimate_sampler_ess", "estimate_mmd_with_model",
+                     "compute_ssim_metric", "estimate_sampler_ess", "estimate_mmd_with_model",
                      "estimate_mmd_for_full_chain", "estimate_iwelbo", "estimate_kl_div_for_full_chain",
                      "estimate_kl_div", "estimate_fid_chain", "estimate_kid_chain", "estimate_mog_kldivs",
                      "estimate_sampler_variance", "save_img_snapshot_in_tb")
@@ -164,6 +165,35 @@ class TestVAESamplerBase(HyperparametersMixin):
         pass
 
     def test_epoch_end(self, outputs):
+        """Aggregation of test_step_vae_sampling.py:824-858 without TensorBoard: scalar series are
+        averaged over batches weighted by batch size; point-wise metrics [t, n, k] give per-iteration
+        mean / std over chains (of the mean over data) and quantiles over (n k).  The summary is
+        returned and, when ``out_dir`` is set, saved as ``metrics_summary.npz``."""
+        num_X = np.array(self.metrics.get('num_X', []), dtype=np.float64)
+        summary = {}
+        for key, values in self.metrics.items():
+            if key == 'num_X' or len(values) == 0:
+                continue
+            if key.startswith('imp_metric/'):
+                name = key.split('imp_metric/')[1]
+                v = np.concatenate(values, axis=1).transpose(1, 2, 0)       # t n k -> n k t
+                over_data = v.mean(axis=0)                                   # k t
+                summary[f'{name}/mean/test'] = over_data.mean(axis=0)
+                summary[f'{name}/std/test'] = (over_data.std(axis=0, ddof=1) if over_data.shape[0] != 1
+                                               else np.ones_like(over_data.mean(axis=0)))
+                qs = self.hparams.imputation_metric_quantiles
+                if len(qs):
+                    quant = np.quantile(v.reshape(-1, v.shape[-1]), axis=0, q=qs)
+                    for i, q in enumerate(qs):
+                        summary[f'{name}/q{q}/test'] = quant[i]
+            else:
+                m = np.array(values, dtype=np.float64)
+                summary[f'{key}/test'] = (m * num_X[:, None]).sum(axis=0) / num_X.sum()
+        self.metrics_summary = summary
+        if self.out_dir is not None and summary:
+            os.makedirs(self.out_dir, exist_ok=True)
+            np.savez_compressed(os.path.join(self.out_dir, 'metrics_summary.npz'),
+                                **{k.replace('/', '__'): v for k, v in summary.items()})
         return outputs
 
     # ---- random draws -------------------------------------------------------------------
@@ -225,6 +255,17 @@ class TestVAESamplerBase(HyperparametersMixin):
         X_true1 = X_true.unsqueeze(1)
         hp = self.hparams
         imputations, latents = [], ([] if hp.store_latents else None)
+        metrics = defaultdict(list)
+        # point-wise diagnostics accumulate in device buffers [T, B, K]; one transfer at the end
+        T_max, B = self.max_iterations, X.shape[0]
+        point = {}
+        for flag, name in (('compute_rmse_metric', 'rmse'), ('compute_mae_metric', 'mae'),
+                           ('compute_latent_wass_metric', 'latent_wass')):
+            if hp.get(flag):
+                point[name] = torch.empty(T_max, B, K, device=dev, dtype=torch.float32)
+        q_true = None
+        if 'latent_wass' in point:
+            q_true = imputation_metrics.encode_posterior(self.model, torch.nan_to_num(X_true1))
         self._iteration = 0
         X = self.basic_imputation(X, M)
         imputations.append(X.clone())
@@ -232,6 +273,12 @@ class TestVAESamplerBase(HyperparametersMixin):
         outputs = None
         for t, outputs in enumerate(self.sampler(X, M)):
             X = outputs['X']
+            if 'rmse' in point:
+                imputation_metrics.imputation_rmse_metric(X, X_true1, M, out=point['rmse'][t])
+            if 'mae' in point:
+                imputation_metrics.imputation_mae_metric(X, X_true1, M, out=point['mae'][t])
+            if 'latent_wass' in point:
+                imputation_metrics.imputation_latent_wass(X, X_true1, self.model, q_true=q_true, out=point['latent_wass'][t])
             if ((hp.store_last_n_iterations == -1 or (self.max_iterations - hp.store_last_n_iterations) <= t)
                     and t % hp.store_every_n_iterations == 0):
                 imputations.append(X.clone())
@@ -240,7 +287,7 @@ class TestVAESamplerBase(HyperparametersMixin):
             for key, val in outputs.items():
                 if key in ('X', 'Z', 'is_ess_not_reduced', 'total_num_props') or key.startswith('_'):
                     continue
-                self.metrics[key].append(val)
+                metrics[key].append(val)
         if t >= 0 and ((hp.store_last_n_iterations == -1 or (self.max_iterations - hp.store_last_n_iterations) <= t)
                        and not (t % hp.store_every_n_iterations == 0)):
             imputations.append(X.clone())
@@ -257,7 +304,13 @@ class TestVAESamplerBase(HyperparametersMixin):
             np.savez_compressed(os.path.join(self.out_dir, f'imputations_{batch_idx}.npz'),
                                 imputations=imps, latents=lat, true_X=X_true1.cpu().numpy(),
                                 masks=M.cpu().numpy(), data_idx=np.asarray(I.cpu() if torch.is_tensor(I) else I))
-        return {k: [float(v) if not torch.is_tensor(v) else float(v) for v in vals] for k, vals in self.metrics.items()}
+        out = {k: [float(v) for v in vals] for k, vals in metrics.items()}   # device scalars: read once, here
+        for name, buf in point.items():
+            out[f'imp_metric/{name}'] = buf[:t + 1].cpu().numpy()
+        for key, value in out.items():
+            self.metrics[key].append(value)
+        self.metrics['num_X'].append(X_true.shape[0])
+        return out
 
 
 class TestVAELatentAdaptiveImportanceResampling(TestVAESamplerBase):

@@ -36,6 +36,49 @@ struct CsConvArgs {
   int64_t npix;  // n * hout * wout
 };
 
+// Epilogue of the matrix-core convolutions: the lane holds pixel `gp`; register quad q of tile ct
+// holds channels co0 + 32ct + 8q + 4h + 0..3.  Bias, residual and ReLU are applied here.
+template <int CT>
+__device__ __forceinline__ void conv_store(const CsConvArgs& a, const f32x16 (&acc)[CT], int64_t gp, int co0, int h) {
+  if (gp >= a.npix) return;
+  if ((a.cout & 31) == 0 && !a.out_nchw) {
+    float* orow = a.out + gp * a.cout + co0;
+    const float* rrow = a.res ? a.res + gp * a.cout + co0 : nullptr;
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int c = ct * 32 + 8 * q + 4 * h;
+        f32x4 v = {acc[ct][4 * q], acc[ct][4 * q + 1], acc[ct][4 * q + 2], acc[ct][4 * q + 3]};
+        if (a.bias) v += *(const f32x4*)(a.bias + co0 + c);
+        if (rrow) v += *(const f32x4*)(rrow + c);
+        if (a.relu) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.0f);
+        }
+        *(f32x4*)(orow + c) = v;
+      }
+  } else {
+    const int hw = a.hout * a.wout;
+    const int64_t n = gp / hw;
+    const int rem = (int)(gp - n * hw);
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + ct * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
+        if (co < a.cout) {
+          float v = acc[ct][r];
+          if (a.bias) v += a.bias[co];
+          if (a.res) v += a.res[gp * a.cout + co];
+          if (a.relu) v = fmaxf(v, 0.0f);
+          if (a.out_nchw) a.out[(n * a.cout + co) * hw + rem] = v;
+          else a.out[gp * a.cout + co] = v;
+        }
+      }
+  }
+}
+
 // Block = 4 wavefronts = 128 output pixels x (32*CT) output channels; a wavefront owns 32 pixels.
 // D[cout][pixel] = sum_k W[cout][k] * act[pixel][k]: the A operand is the weight tile, the B
 // operand the activation tile, so a lane ends up with 4 consecutive output channels of one pixel
@@ -149,49 +192,117 @@ __global__ void __launch_bounds__(256) cs_conv_mfma_kernel(const CsConvArgs a) {
     }
   }
 
-  // epilogue: lane = pixel, register quad q of tile ct = channels 32ct + 8q + 4h + 0..3
 #pragma unroll
-  for (int pt = 0; pt < PT; ++pt) {
-    const int64_t gp = (int64_t)blockIdx.x * NPIX + wave * 32 * PT + pt * 32 + l31;
-    if (gp >= a.npix) continue;
-    const int co0 = blockIdx.y * (CT * 32);
-    if ((a.cout & 31) == 0 && !a.out_nchw) {
-      float* orow = a.out + gp * a.cout + co0;
-      const float* rrow = a.res ? a.res + gp * a.cout + co0 : nullptr;
+  for (int pt = 0; pt < PT; ++pt)
+    conv_store<CT>(a, acc[pt], (int64_t)blockIdx.x * NPIX + wave * 32 * PT + pt * 32 + l31, blockIdx.y * (CT * 32), h);
+}
+
+// 3x3, stride 1, pad 1 convolutions that keep the spatial size (most layers of the ResNets): output
+// pixels and input pixels share one linear index, so the 9 taps of a block's 128 output pixels
+// read one contiguous window of 128 + 2(W+1) input pixels.  That window ("halo tile") is staged in
+// LDS ONCE per 32-channel chunk and reused by all 9 taps (per-lane row offset kh*W + kw, zeroed
+// where the tap leaves the image), which cuts the activation traffic of the generic kernel ~6x;
+// the 9 weight tiles of the chunk stream through a two-stage LDS ring (one barrier per tap).
+template <int CT>
+__global__ void __launch_bounds__(256) cs_conv3x3_halo_kernel(const CsConvArgs a, int NR, int NP) {
+  constexpr int RS = 36, W_F = CT * 32 * RS;
+  extern __shared__ __attribute__((aligned(16))) float s_dyn[];
+  float* s_w = s_dyn;              // [2][CT*32][RS]
+  float* s_halo = s_dyn + 2 * W_F; // [NR][RS]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = lane >> 5, l31 = lane & 31, c4 = tid & 7;
+  const int W = a.win, H = a.hin;
+  const int ncc = a.cin >> 5;
+  const int64_t p0 = (int64_t)blockIdx.x * 128;
+  const float* wblk = a.w + (int64_t)blockIdx.y * (CT * 32) * 32;
+
+  // which of the 9 taps stay inside the image for this lane's output pixel
+  const int64_t gp = p0 + wave * 32 + l31;
+  unsigned tapmask = 0;
+  {
+    const int hw = H * W;
+    const int64_t g = gp < a.npix ? gp : 0;
+    const int rem = (int)(g % hw);
+    const int oh = rem / W, ow = rem - oh * W;
 #pragma unroll
-      for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int c = ct * 32 + 8 * q + 4 * h;
-          f32x4 v = {acc[pt][ct][4 * q], acc[pt][ct][4 * q + 1], acc[pt][ct][4 * q + 2], acc[pt][ct][4 * q + 3]};
-          if (a.bias) v += *(const f32x4*)(a.bias + co0 + c);
-          if (rrow) v += *(const f32x4*)(rrow + c);
-          if (a.relu) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.0f);
-          }
-          *(f32x4*)(orow + c) = v;
-        }
-    } else {
-      const int hw = a.hout * a.wout;
-      const int64_t n = gp / hw;
-      const int rem = (int)(gp - n * hw);
-#pragma unroll
-      for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int co = co0 + ct * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
-          if (co < a.cout) {
-            float v = acc[pt][ct][r];
-            if (a.bias) v += a.bias[co];
-            if (a.res) v += a.res[gp * a.cout + co];
-            if (a.relu) v = fmaxf(v, 0.0f);
-            if (a.out_nchw) a.out[(n * a.cout + co) * hw + rem] = v;
-            else a.out[gp * a.cout + co] = v;
-          }
-        }
+    for (int t = 0; t < 9; ++t) {
+      const int ih = oh + t / 3 - 1, iw = ow + t % 3 - 1;
+      if (gp < a.npix && ih >= 0 && ih < H && iw >= 0 && iw < W) tapmask |= 1u << t;
     }
   }
+
+  f32x16 acc[CT];
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[ct][r] = 0.0f;
+
+  constexpr int NPMAX = 8;  // halo rows * 8 float4 / 256 threads, W + 1 <= 64
+  f32x4 rh[NPMAX], rw[CT];
+  auto fetch_halo = [&](int cc) {
+#pragma unroll
+    for (int p = 0; p < NPMAX; ++p) {
+      const int row = (tid >> 3) + 32 * p;
+      const int64_t q = p0 - (W + 1) + row;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (p < NP && row < NR && q >= 0 && q < a.npix) v = *(const f32x4*)(a.in + q * a.cin + cc * 32 + c4 * 4);
+      rh[p] = v;
+    }
+  };
+  auto stash_halo = [&]() {
+#pragma unroll
+    for (int p = 0; p < NPMAX; ++p) {
+      const int row = (tid >> 3) + 32 * p;
+      if (p < NP && row < NR) *(f32x4*)(s_halo + row * RS + c4 * 4) = rh[p];
+    }
+  };
+  auto fetch_w = [&](int t) {
+    const float* wt = wblk + (int64_t)t * a.cout_p * 32;
+#pragma unroll
+    for (int i = 0; i < CT; ++i) rw[i] = *(const f32x4*)(wt + (tid + 256 * i) * 4);
+  };
+  auto stash_w = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < CT; ++i) {
+      const int idx = tid + 256 * i;
+      *(f32x4*)(s_w + buf * W_F + (idx >> 3) * RS + (idx & 7) * 4) = rw[i];
+    }
+  };
+
+  fetch_halo(0);
+  fetch_w(0);  // tap 0 of chunk 0
+  int step = 0;
+  for (int cc = 0; cc < ncc; ++cc) {
+    __syncthreads();  // every read of the previous halo tile is done
+    stash_halo();
+    for (int tap = 0; tap < 9; ++tap, ++step) {
+      const int buf = step & 1;
+      stash_w(buf);  // this stage was last read two steps ago, behind the previous step's barrier
+      __syncthreads();
+      if (tap < 8) {
+        fetch_w((tap + 1) * ncc + cc);
+      } else if (cc + 1 < ncc) {
+        fetch_w(cc + 1);
+        fetch_halo(cc + 1);
+      }
+      const float* sp = s_halo + (wave * 32 + l31 + (tap / 3) * W + (tap % 3)) * RS + 4 * h;
+      const float* sw = s_w + buf * W_F + l31 * RS + 4 * h;
+      const bool inside = (tapmask >> tap) & 1u;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        f32x4 b = *(const f32x4*)(sp + 8 * g);
+        if (!inside) b = f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 w[CT];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) w[ct] = *(const f32x4*)(sw + ct * 32 * RS + 8 * g);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int ct = 0; ct < CT; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[ct][j], b[j], acc[ct], 0, 0, 0);
+      }
+    }
+  }
+  conv_store<CT>(a, acc, gp, blockIdx.y * (CT * 32), h);
 }
 
 // V output channels per thread (channel fastest): any channel counts, either memory order.  V = 4
@@ -407,12 +518,21 @@ int launch_conv(const CsProgram& p, const CsLayer& L, const float* in, const flo
   a.cout_p = (d.cout + 31) & ~31;
   if (L.wp_off >= 0) {
     a.w = p.d_blob + L.wp_off;
+    const bool halo = d.ksize == 3 && d.stride == 1 && d.pad == 1 && d.upsample == 1 && d.hin == d.hout &&
+                      d.win == d.wout && d.cin % 32 == 0 && d.win + 1 <= 64;
+    const int NR = 128 + 2 * (d.win + 1), NP = (NR * 8 + 255) / 256;
 #define CS_CONV_LAUNCH(CT_)                                                                               \
   do {                                                                                                    \
-    const size_t lds = (size_t)(128 + CT_ * 32) * 36 * sizeof(float);                                     \
     const unsigned gx = (unsigned)((a.npix + 127) / 128);                                                 \
-    hipLaunchKernelGGL((cs_conv_mfma_kernel<CT_, 1>), dim3(gx, a.cout_p / (32 * CT_)), dim3(256), lds,    \
-                       stream, a);                                                                        \
+    if (halo && (size_t)(2 * CT_ * 32 + NR) * 36 * sizeof(float) <= 64 * 1024) {                          \
+      const size_t lds = (size_t)(2 * CT_ * 32 + NR) * 36 * sizeof(float);                                \
+      hipLaunchKernelGGL((cs_conv3x3_halo_kernel<CT_>), dim3(gx, a.cout_p / (32 * CT_)), dim3(256), lds,  \
+                         stream, a, NR, NP);                                                              \
+    } else {                                                                                              \
+      const size_t lds = (size_t)(128 + CT_ * 32) * 36 * sizeof(float);                                   \
+      hipLaunchKernelGGL((cs_conv_mfma_kernel<CT_, 1>), dim3(gx, a.cout_p / (32 * CT_)), dim3(256), lds,  \
+                         stream, a);                                                                      \
+    }                                                                                                     \
   } while (0)
     // Measured on the Omniglot / MNIST-GMM nets: 128-pixel x 128-channel blocks (two blocks per CU)
     // beat 256-pixel blocks, 64-channel blocks and a two-stage LDS ring by 2-7 %.

@@ -310,6 +310,20 @@ __global__ void __launch_bounds__(256) cs_conv3x3_halo_kernel(const CsConvArgs a
 // their output writes.
 template <int V>
 __global__ void __launch_bounds__(256) cs_conv_direct_kernel(const CsConvArgs a) {
+  // small weight sets (the first convolution: 64 x 1 x 3 x 3) are staged in LDS as [tap][ci][cout],
+  // so a thread's V output channels come from one 16-byte LDS read per (tap, ci)
+  constexpr int LDS_W = 4096;
+  __shared__ __attribute__((aligned(16))) float s_w[LDS_W];
+  const int kk = a.ksize * a.ksize;
+  const bool staged = V == 4 && a.cout * a.cin * kk <= LDS_W;
+  if (staged) {
+    for (int i = threadIdx.x; i < a.cout * a.cin * kk; i += 256) {
+      const int co = i / (a.cin * kk), r = i - co * (a.cin * kk);  // r = ci*kk + tap
+      const int ci = r / kk, tap = r - ci * kk;
+      s_w[(tap * a.cin + ci) * a.cout + co] = a.w[i];
+    }
+    __syncthreads();
+  }
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int cv = a.cout / V;
   if (idx >= a.npix * cv) return;
@@ -320,7 +334,6 @@ __global__ void __launch_bounds__(256) cs_conv_direct_kernel(const CsConvArgs a)
   const int rem = (int)(gp - n * hw);
   const int oh = rem / a.wout, ow = rem - oh * a.wout;
   const int hup = a.hin << a.us, wup = a.win << a.us;
-  const int kk = a.ksize * a.ksize;
   const int64_t wstride = (int64_t)a.cin * kk;  // between output channels
   float s[V];
 #pragma unroll
@@ -332,13 +345,20 @@ __global__ void __launch_bounds__(256) cs_conv_direct_kernel(const CsConvArgs a)
       const int uw = ow * a.stride - a.pad + kw;
       if (uw < 0 || uw >= wup) continue;
       const int sh = uh >> a.us, sw = uw >> a.us;
-      const float* wp = a.w + (int64_t)co * wstride + kh * a.ksize + kw;
+      const int tap = kh * a.ksize + kw;
+      const float* wp = a.w + (int64_t)co * wstride + tap;
       const float* ip = a.in_nchw ? a.in + (n * a.cin * a.hin + sh) * a.win + sw : a.in + ((n * a.hin + sh) * a.win + sw) * a.cin;
       const int64_t istride = a.in_nchw ? (int64_t)a.hin * a.win : 1;
       for (int ci = 0; ci < a.cin; ++ci) {
         const float x = ip[ci * istride];
+        if (V == 4 && staged) {
+          const f32x4 w4 = *(const f32x4*)(s_w + (tap * a.cin + ci) * a.cout + co);
 #pragma unroll
-        for (int v = 0; v < V; ++v) s[v] = fmaf(x, wp[v * wstride + (int64_t)ci * kk], s[v]);
+          for (int v = 0; v < V; ++v) s[v] = fmaf(x, w4[v & 3], s[v]);
+        } else {
+#pragma unroll
+          for (int v = 0; v < V; ++v) s[v] = fmaf(x, wp[v * wstride + (int64_t)ci * kk], s[v]);
+        }
       }
     }
   }

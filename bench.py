@@ -157,6 +157,8 @@ def main():
     enc_tf = enc_flops / (enc_ms * 1e-3) / 1e12
     dec_tf = dec_flops / (dec_ms * 1e-3) / 1e12
     value = world * B * K * args.steps / elapsed
+    Kp = K + R
+    res_bytes = (Kp * 2 * Zd * 4 + Kp * Zd * 4 + Kp * 4 + K * (2 * D * 4 + D * 4) + D) + (K * D * 4 + 2 * Kp * 4 + Kp * 8 + 12)
 
     # HBM bytes per encoder launch from the PMC counters of a profiled run of this command
     # (tools/pmc_summary.py writes the file; null when it has not been collected)
@@ -181,6 +183,9 @@ def main():
                      "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": enc_tf / F32_MFMA_PEAK_TFLOPS,
                      "traffic": traffic, "flops_per_launch": enc_flops, "avg_launch_ms": enc_ms},
         "kernels": {"encoder_ms": enc_ms, "decoder_ms": dec_ms, "resample_impute_ms": res_ms,
+                    # HBM-bound stage: algorithmic bytes per example (q, Z, gen_ll, the K chosen generator rows,
+                    # X and M read; X, log-weights, normalised weights, indices, statistics written)
+                    "resample_impute_GBps": B * res_bytes / (res_ms * 1e-3) / 1e9, "resample_impute_bytes_per_example": res_bytes,
                     "decoder_tflops": dec_tf, "decoder_frac": dec_tf / F32_MFMA_PEAK_TFLOPS,
                     "step_flops": enc_flops + dec_flops,
                     "step_mfma_frac": (enc_flops + dec_flops) / ((enc_ms + dec_ms + res_ms) * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS},

@@ -339,6 +339,7 @@ static int check_cfg(const cs_lair_cfg* c, const cs_lair_bufs* b) {
 
 extern "C" int cs_lair_encode(const cs_mlp_t* enc, const cs_lair_cfg* c, const cs_lair_bufs* b, void* stream) {
   if (int rc = check_cfg(c, b)) return rc;
+  if (c->B == 0) return CS_OK;  // empty batch: nothing to do (its tensors have no storage)
   CS_REQUIRE(enc && b->X && b->q, "null argument");
   CS_REQUIRE(enc->dev.in_dim == c->D && enc->dev.out_dim == 2 * c->Zd && enc->dev.split == 2,
              "encoder shape does not match the configuration");
@@ -358,6 +359,7 @@ extern "C" int cs_lair_encode(const cs_mlp_t* enc, const cs_lair_cfg* c, const c
 extern "C" int cs_lair_decode(const cs_mlp_t* dec, const cs_lair_cfg* c, const cs_lair_bufs* b, const cs_rng* rng,
                               void* stream) {
   if (int rc = check_cfg(c, b)) return rc;
+  if (c->B == 0) return CS_OK;  // empty batch: nothing to do (its tensors have no storage)
   CS_REQUIRE(dec && b->X && b->M && b->q && b->Z && b->gen && b->gen_ll, "null argument");
   const bool bern = c->gen_dist == CS_DIST_BERN;
   CS_REQUIRE(dec->dev.in_dim == c->Zd && dec->dev.out_dim == (bern ? 1 : 2) * c->D &&
@@ -384,6 +386,7 @@ extern "C" int cs_lair_decode(const cs_mlp_t* dec, const cs_lair_cfg* c, const c
 
 extern "C" int cs_lair_resample_impute(const cs_lair_cfg* c, const cs_lair_bufs* b, const cs_rng* rng, void* stream) {
   if (int rc = check_cfg(c, b)) return rc;
+  if (c->B == 0) return CS_OK;  // empty batch: nothing to do (its tensors have no storage)
   CS_REQUIRE(b->X && b->M && b->q && b->Z && b->gen && b->gen_ll && b->log_w && b->norm_log_w && b->idx &&
                  b->ess && b->tess && b->perplexity,
              "null argument");

@@ -288,6 +288,10 @@ int cs_rng_uniform64(const cs_rng* rng, uint32_t stream_id, int64_t rows, int32_
  * writes 16 int64 per 16-row tile into buf (device memory, 16*ceil(rows/16) int64): clock stamps in
  * slots 0..14, (XCC_ID << 32 | HW_ID) of the wavefront in slot 15. */
 int cs_debug_set_trace(long long* buf);
+/* Test hook (no counterpart in the reference): bound in bytes of the activation workspace of
+ * layer-program networks, which decides how many rows one pass processes; 0 restores the default
+ * (6 GiB). */
+int cs_debug_set_workspace_budget(int64_t bytes);
 
 #ifdef __cplusplus
 }

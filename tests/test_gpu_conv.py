@@ -140,3 +140,46 @@ def test_yaml_driver_end_to_end_conv_configs(tmp_path):
     assert f0["imputations"].shape == (5, 10, 4, 196) and np.isfinite(f0["imputations"]).all()
     f1 = np.load(os.path.join(tester.out_dir, "irwg_imputations_after_final_resampling_0.npz"))
     assert f1["imputations"].shape == (1, 10, 4 * 5, 196) and np.isfinite(f1["imputations"]).all()
+
+
+def test_row_chunking_of_the_workspace_gives_identical_results():
+    """Layer programs process rows in chunks bounded by a workspace budget; a budget of a few rows
+    must reproduce the single-pass results bit for bit (row offsets of every stage / finish kernel)."""
+    from vae_conditional_sampling_amd import _lib
+    from vae_conditional_sampling_amd.sampling.vae_imputation import importance_resampling_gibbs_iteration
+    fx = load_golden("conv_lair_gmm_like")
+    B, K, R, I, D, Zd, iters, seed = [int(v) for v in fx["cfg"]]
+    enc_w, dec_w = conv_weights(str(fx["net"]), seed)
+    X = torch.from_numpy(fx["X0"]).cuda()
+    M = torch.from_numpy(fx["M"]).cuda()
+    outs = []
+    try:
+        for budget in (0, 600_000):  # default; ~4 rows per pass of these nets
+            _lib.check(_lib.lib().cs_debug_set_workspace_budget(budget))
+            model = make_conv_model(str(fx["net"]), enc_w, dec_w, "normal_with_eps", "normal_with_eps")
+            o = importance_resampling_gibbs_iteration(model, X, M, I, num_prior_replenish_proposals=R,
+                                                      rng=_lib.make_rng(5, 1, 0))
+            outs.append([o[0].clone(), o[6].clone(), o[7].clone()])
+    finally:
+        _lib.check(_lib.lib().cs_debug_set_workspace_budget(0))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+
+
+def test_multi_channel_images_take_the_channel_major_path():
+    """3-channel inputs / outputs (not in the reference's configurations, allowed by its classes)."""
+    from oracle import cs_oracle_conv as OC
+    from vae_conditional_sampling_amd.models.vae_resnet import ResNetDecoder, ResNetEncoder
+    ecfg = dict(input_shape=(3, 8, 8), layers=[1, 1], layer_widths=[32, 64], latent_dim=12)
+    dcfg = dict(output_shape=(3, 8, 8), layers=[1, 1], layer_upscale=[None, None], layer_widths=[32, 32],
+                downscaled_resolution=(4, 4), latent_dim=6, upscale_factor=2)
+    enc_w = OC.make_resnet_encoder_weights(seed=3, **ecfg)
+    dec_w = OC.make_resnet_decoder_weights(seed=4, **dcfg)
+    enc, dec = ResNetEncoder(**ecfg), ResNetDecoder(**dcfg)
+    enc.load_state_dict(OC.state_dict_of(enc_w), strict=True)
+    dec.load_state_dict(OC.state_dict_of(dec_w), strict=True)
+    enc.out_split = dec.out_split = 1
+    g = torch.Generator().manual_seed(1)
+    x, z = torch.randn(5, 192, generator=g), torch.randn(5, 6, generator=g)
+    assert_close(enc.cuda().eval()(x.cuda()), OC.resnet_encoder_forward(enc_w, x), "encoder", CONV_RTOL)
+    assert_close(dec.cuda().eval()(z.cuda()), OC.resnet_decoder_forward(dec_w, z), "decoder", CONV_RTOL)

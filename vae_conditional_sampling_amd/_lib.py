@@ -119,6 +119,7 @@ def lib():
     L.cs_final_resample.argtypes = [vp, vp, i64, i64, i32, i32, vp, C.POINTER(cs_rng), i64, vp, vp, vp, vp]
     L.cs_stdnormal_logprob_rows.argtypes = [vp, i64, i32, vp, vp]
     L.cs_decode_params.argtypes = [vp, vp, i64, i32, vp, vp]
+    L.cs_debug_set_workspace_budget.argtypes = [i64]
     L.cs_imputation_errors.argtypes = [vp, vp, vp, i64, i32, i32, vp, vp, vp]
     L.cs_latent_wasserstein.argtypes = [vp, vp, i64, i32, i32, vp, vp]
     L.cs_sample_impute.argtypes = [vp, i32, vp, C.POINTER(cs_rng), u32, vp, vp, i64, i32, i32, vp, vp, i32, vp]

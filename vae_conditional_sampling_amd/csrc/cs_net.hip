@@ -578,7 +578,7 @@ bool mfma_eligible(const cs_layer_desc& d) {
   return (d.op == CS_OP_CONV || d.op == CS_OP_LINEAR) && d.cin >= 16 && !(d.in_nchw && d.cin > 1);
 }
 
-constexpr int64_t kWorkspaceBudgetBytes = (int64_t)6 << 30;
+int64_t g_workspace_budget_bytes = (int64_t)6 << 30;
 
 }  // namespace
 
@@ -586,6 +586,12 @@ int cs_dec_stage_launch(const CsMlpArgs& a, int64_t row0, int64_t rows, hipStrea
   const int64_t n = rows * ((a.Zd + 3) / 4);
   hipLaunchKernelGGL(cs_dec_stage_kernel, dim3(blocks_for(n)), dim3(256), 0, stream, a, row0, rows);
   CS_HIP(hipGetLastError());
+  return CS_OK;
+}
+
+extern "C" int cs_debug_set_workspace_budget(int64_t bytes) {
+  CS_REQUIRE(bytes >= 0, "negative budget");
+  g_workspace_budget_bytes = bytes ? bytes : ((int64_t)6 << 30);
   return CS_OK;
 }
 
@@ -706,7 +712,7 @@ int cs_prog_launch(const CsMlpArgs& a, hipStream_t stream) {
     prefix[b] = per_row;
     per_row += (p->buf_elems[b] + 3) & ~(int64_t)3;  // keep every buffer 16-byte aligned
   }
-  int64_t chunk = kWorkspaceBudgetBytes / (per_row * 4);
+  int64_t chunk = g_workspace_budget_bytes / (per_row * 4);
   if (chunk < 1) chunk = 1;
   if (chunk > a.rows) chunk = a.rows;
   chunk = (chunk + 3) & ~(int64_t)3;

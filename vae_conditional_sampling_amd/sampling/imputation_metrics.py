@@ -14,18 +14,28 @@ from .. import _lib
 from . import engine
 
 
-def _prep(X_imp, X_true, M):
+class PreparedTruth:
+    """The per-batch constants of the diagnostics, prepared once: X_true with NaNs zeroed [B,D], the
+    mask as bytes [B,D], and (lazily) the posterior of the true data for the latent distance."""
+
+    def __init__(self, X_true, M, like):
+        B, K, D = like.shape
+        self.Xt = torch.nan_to_num(X_true.reshape(B, D).to(like.device, torch.float32)).contiguous()
+        self.M8 = engine.mask_u8(M)
+        self.q_true = None
+
+
+def imputation_errors(X_imp, truth, *, rmse=None, mae=None):
+    """RMSE and / or MAE of one iteration in one launch, written into the given [B,K] tensors."""
     B, K, D = X_imp.shape
-    Xt = torch.nan_to_num(X_true.reshape(B, D).to(X_imp.device, torch.float32)).contiguous()
-    return B, K, D, X_imp.contiguous(), Xt, engine.mask_u8(M)
+    _lib.check(_lib.lib().cs_imputation_errors(_lib.ptr(X_imp.contiguous()), _lib.ptr(truth.Xt), _lib.ptr(truth.M8), B, K, D,
+                                               _lib.ptr(rmse), _lib.ptr(mae), _lib.current_stream()))
 
 
 def _errors(X_imp, X_true, M, want_rmse, out):
-    B, K, D, X, Xt, M8 = _prep(X_imp, X_true, M)
-    out = out if out is not None else torch.empty(B, K, device=X.device, dtype=torch.float32)
-    _lib.check(_lib.lib().cs_imputation_errors(_lib.ptr(X), _lib.ptr(Xt), _lib.ptr(M8), B, K, D,
-                                               _lib.ptr(out) if want_rmse else None,
-                                               None if want_rmse else _lib.ptr(out), _lib.current_stream()))
+    B, K, D = X_imp.shape
+    out = out if out is not None else torch.empty(B, K, device=X_imp.device, dtype=torch.float32)
+    imputation_errors(X_imp, PreparedTruth(X_true, M, X_imp), **({"rmse": out} if want_rmse else {"mae": out}))
     return out
 
 

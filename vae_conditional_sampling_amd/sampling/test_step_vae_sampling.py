@@ -263,9 +263,10 @@ class TestVAESamplerBase(HyperparametersMixin):
                            ('compute_latent_wass_metric', 'latent_wass')):
             if hp.get(flag):
                 point[name] = torch.empty(T_max, B, K, device=dev, dtype=torch.float32)
+        truth = imputation_metrics.PreparedTruth(X_true1, M, X) if point else None
         q_true = None
         if 'latent_wass' in point:
-            q_true = imputation_metrics.encode_posterior(self.model, torch.nan_to_num(X_true1))
+            q_true = imputation_metrics.encode_posterior(self.model, truth.Xt.unsqueeze(1))
         self._iteration = 0
         X = self.basic_imputation(X, M)
         imputations.append(X.clone())
@@ -273,10 +274,9 @@ class TestVAESamplerBase(HyperparametersMixin):
         outputs = None
         for t, outputs in enumerate(self.sampler(X, M)):
             X = outputs['X']
-            if 'rmse' in point:
-                imputation_metrics.imputation_rmse_metric(X, X_true1, M, out=point['rmse'][t])
-            if 'mae' in point:
-                imputation_metrics.imputation_mae_metric(X, X_true1, M, out=point['mae'][t])
+            if 'rmse' in point or 'mae' in point:  # one launch for both
+                imputation_metrics.imputation_errors(X, truth, rmse=point['rmse'][t] if 'rmse' in point else None,
+                                                     mae=point['mae'][t] if 'mae' in point else None)
             if 'latent_wass' in point:
                 imputation_metrics.imputation_latent_wass(X, X_true1, self.model, q_true=q_true, out=point['latent_wass'][t])
             if ((hp.store_last_n_iterations == -1 or (self.max_iterations - hp.store_last_n_iterations) <= t)

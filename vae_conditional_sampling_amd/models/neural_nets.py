@@ -41,6 +41,7 @@ class ResidualFCNetwork(nn.Module):
         self.out_split = 2  # (loc | raw scale); the VAE sets 1 for Bernoulli logits
         self._packed = None
         self._packed_key = None
+        self._tensors = None
         self.requires_grad_(False)
 
     @property
@@ -65,8 +66,11 @@ class ResidualFCNetwork(nn.Module):
 
     def packed(self):
         """Device handle of the packed network (built lazily, rebuilt when weights change)."""
-        key = (tuple((p.data_ptr(), p._version) for p in self.parameters()), self.out_split,
-               torch.cuda.current_device())
+        # called every sampler iteration: the tensor list is gathered once (module traversal is the
+        # expensive part), storage pointers and version counters detect .to() / load_state_dict / in-place edits
+        if self._tensors is None:
+            self._tensors = list(self.parameters())
+        key = (tuple((p.data_ptr(), p._version) for p in self._tensors), self.out_split, torch.cuda.current_device())
         if self._packed is None or self._packed_key != key:
             w = self.weight_dict()
             half = self.output_dim // self.out_split

@@ -72,12 +72,14 @@ class _ProgramNet(nn.Module):
     def _init_cache(self):
         self._packed = None
         self._packed_key = None
+        self._tensors = None
         self.requires_grad_(False)
 
     def packed(self):
         """Device handle of the layer program (built lazily, rebuilt when weights change)."""
-        tensors = list(self.parameters()) + list(self.buffers())
-        key = (tuple((t.data_ptr(), t._version) for t in tensors), self.out_split, torch.cuda.current_device())
+        if self._tensors is None:  # gathered once: module traversal is the expensive part of this check
+            self._tensors = list(self.parameters()) + list(self.buffers())
+        key = (tuple((t.data_ptr(), t._version) for t in self._tensors), self.out_split, torch.cuda.current_device())
         if self._packed is None or self._packed_key != key:
             self._packed = self._program().build()
             self._packed_key = key

@@ -185,9 +185,22 @@ typedef struct {
   int32_t hist_len;  /* ring capacity (max_history_length) */
   int32_t hist_tail; /* slot of the newest entry before this call */
   int32_t hist_full; /* 1 once the ring has wrapped */
-  int32_t reserved;
+  int32_t flags;     /* CS_MWG_* bits below; 0 = AC-MWG as published */
   double prior_mixture_probability;
 } cs_acmwg_cfg;
+
+/* Variants of the Metropolis-within-Gibbs step that share the AC-MWG kernels.
+ * CS_MWG_PROPOSE_FROM_CURRENT: the proposal conditions on the chain's current imputation instead
+ *   of a historical one (TestVAEMetropolisWithinGibbs.sampler, test_step_vae_sampling.py:1221);
+ *   no history is read or written: ring, avail, r_hist, slots and in_off may be NULL.
+ * CS_MWG_JOINT_TARGET_NEW: the proposal's log-likelihood sums over all D dimensions of the current
+ *   imputation, not only the observed ones (:1245; ablation_use_mwg_target :1722-1723).
+ * CS_MWG_JOINT_TARGET_OLD: the same for the log-likelihood kept for the next step (:1217,1269;
+ *   the AC-MWG ablation uses it for the state after the warm-up only, :1657-1658, and keeps the
+ *   masked sum in its steps, :1755). */
+#define CS_MWG_PROPOSE_FROM_CURRENT 1
+#define CS_MWG_JOINT_TARGET_NEW 2
+#define CS_MWG_JOINT_TARGET_OLD 4
 
 typedef struct {
   float* X;         /* [B,K,D] imputations, updated in place */
@@ -239,6 +252,11 @@ int cs_history_set_available(int64_t* avail, const uint8_t* mask, int64_t chains
 /* out[row] = sum_d log N(Z[row,d]; 0, 1): reduce(prior_distr.log_prob(Z), '... d -> ...', 'sum')
  * (test_step_vae_sampling.py:1655). */
 int cs_stdnormal_logprob_rows(const float* Z, int64_t rows, int32_t Zd, float* out, void* stream);
+/* out[b,k] = sum_d w_d log p(X[b,k,d] | gen[b,k]) with w = M[b,:] (NULL: all ones):
+ * reduce(mis_distr.log_prob(X) [*M], '... d -> ...', 'sum') of the chain state after a pseudo-Gibbs
+ * warm-up (test_step_vae_sampling.py:1217,1660).  gen as written by cs_decode_params. */
+int cs_gen_loglik_rows(const float* gen, int32_t gen_dist, const float* X, const uint8_t* M, int64_t B, int32_t K,
+                       int32_t D, float* out, void* stream);
 
 /* Per-iteration imputation diagnostics (test_step_vae_sampling.py:431-445), on the device.
  * rmse[b,k] = sqrt(sum_{d missing} (X[b,k,d] - X_true[b,d])^2 / max(#missing_b, 1))

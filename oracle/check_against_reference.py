@@ -144,17 +144,23 @@ BASE_KW = dict(store_last_n_iterations=-1, store_every_n_iterations=1, imputatio
                imputation_fn="vae_samples")
 
 
-def case_acmwg(ns, name, *, B, K, D, Zd, H, seed, warmup, W, T, p, nkpc=None, cluster=None, R=0):
+def case_acmwg(ns, name, *, B, K, D, Zd, H, seed, warmup, W, T, p, nkpc=None, cluster=None, R=0, plain_mwg=False,
+               ablation=False, clip=False):
+    """AC-MWG sampler class (or, with plain_mwg, TestVAEMetropolisWithinGibbs) against the oracle."""
     from oracle import cs_oracle_samplers as S
     enc = O.make_resfc_weights(D, 2 * Zd, 1, H, seed)
     dec = O.make_resfc_weights(Zd, 2 * D, 1, H, seed + 1)
     vae = ref_vae(ns, enc, dec)
     X, M = make_inputs(B, K, D, seed + 2)
-    kw = dict(num_pseudo_warmup_iterations=W, num_mwg_iterations=T, prior_mixture_probability=p,
-              warmup_method=warmup, num_copies=K, **BASE_KW)
+    kw = dict(num_pseudo_warmup_iterations=W, num_mwg_iterations=T,
+              warmup_method=warmup, num_copies=K, clip_imputations_during_pg_warmup=clip, **BASE_KW)
     if warmup == "irwg":
         kw.update(num_k_per_cluster=nkpc, glr_cluster_size=cluster, num_prior_replenish_proposals=R)
-    tester = ns.test_step.TestVAEAdaptiveCollapsedMetropolisWithinGibbs(**kw)
+    if plain_mwg:
+        tester = ns.test_step.TestVAEMetropolisWithinGibbs(**kw)
+    else:
+        tester = ns.test_step.TestVAEAdaptiveCollapsedMetropolisWithinGibbs(
+            prior_mixture_probability=p, ablation_use_mwg_target=ablation, **kw)
     tester.set_model(vae)
     tape = DrawTape(seed + 3)
     ref_out = []
@@ -166,7 +172,8 @@ def case_acmwg(ns, name, *, B, K, D, Zd, H, seed, warmup, W, T, p, nkpc=None, cl
     src = S.TapeSource(entries)
     okw = dict(num_pseudo_warmup_iterations=W, num_mwg_iterations=T, prior_mixture_probability=p,
                warmup_method=warmup, num_k_per_cluster=nkpc, glr_cluster_size=cluster,
-               num_prior_replenish_proposals=R)
+               num_prior_replenish_proposals=R, plain_mwg=plain_mwg, ablation_use_mwg_target=ablation,
+               clip_imputations_during_pg_warmup=clip)
     ora = list(S.acmwg_sampler(enc, dec, X.clone(), M, src, **okw))
     assert src.pos == len(entries), "oracle did not consume the whole tape"
     assert len(ora) == len(ref_out)
@@ -180,16 +187,49 @@ def case_acmwg(ns, name, *, B, K, D, Zd, H, seed, warmup, W, T, p, nkpc=None, cl
             close(a["Z"], r["Z"], f"Z[{t}]")
         close(torch.as_tensor(a["acceptance"], dtype=torch.float32), torch.as_tensor(r["acceptance"], dtype=torch.float32), "acc")
         if "accepted" in a:
-            accs.append(a["accepted"].numpy()); slots.append(a["slots"].numpy())
+            accs.append(a["accepted"].numpy())
+            if "slots" in a:
+                slots.append(a["slots"].numpy())
     fx.update(X0=X.numpy(), M=M.numpy(),
               cfg=np.array([B, K, D, Zd, H, W, T, nkpc or 0, cluster or 0, R], dtype=np.int64),
-              warmup=np.array(warmup), p=np.float64(p),
+              warmup=np.array(warmup), p=np.float64(p), plain_mwg=np.array(plain_mwg), ablation=np.array(ablation),
+              clip=np.array(clip),
               X_seq=np.stack([r["X"].numpy() for r in ref_out]),
               Z_last=ref_out[-1]["Z"].numpy(),
               acceptance=np.array([float(r["acceptance"]) for r in ref_out], dtype=np.float32),
-              accepted=np.stack(accs), slots=np.stack(slots))
+              accepted=np.stack(accs))
+    if slots:
+        fx["slots"] = np.stack(slots)
     np.savez_compressed(os.path.join(GOLDEN, f"{name}.npz"), **fx)
     print(f"[ok] {name}  (iterations {len(ref_out)}, mean acceptance {np.mean(accs):.2f})")
+
+
+def case_pseudo_gibbs(ns, name, *, B, K, D, Zd, H, seed, T, clip):
+    """TestVAEPseudoGibbs.sampler (test_step_vae_sampling.py:1023-1042) against the oracle."""
+    from oracle import cs_oracle_samplers as S
+    enc = O.make_resfc_weights(D, 2 * Zd, 1, H, seed)
+    dec = O.make_resfc_weights(Zd, 2 * D, 1, H, seed + 1)
+    vae = ref_vae(ns, enc, dec)
+    X, M = make_inputs(B, K, D, seed + 2)
+    tester = ns.test_step.TestVAEPseudoGibbs(num_iterations=T, clip_imputations=clip, num_copies=K, **BASE_KW)
+    tester.set_model(vae)
+    tape = DrawTape(seed + 3)
+    ref_out = []
+    with torch.no_grad(), tape.recording():
+        for o in tester.sampler(X.clone(), M):
+            ref_out.append({k: (v.clone() if torch.is_tensor(v) else v) for k, v in o.items()})
+    src = S.TapeSource(tape.entries)
+    ora = list(S.pseudo_gibbs_sampler(enc, dec, X.clone(), M, src, num_iterations=T, clip_imputations=clip))
+    assert src.pos == len(tape.entries) and len(ora) == len(ref_out) == T
+    for t, (a, r) in enumerate(zip(ora, ref_out)):
+        assert torch.equal(a["X"], r["X"]), f"X[{t}] not bitwise equal"
+        assert torch.equal(a["Z"], r["Z"]), f"Z[{t}] not bitwise equal"
+    fx = dict(flat_weights("enc", enc)); fx.update(flat_weights("dec", dec))
+    fx.update(S.tape_to_npz_dict(tape.entries))
+    fx.update(X0=X.numpy(), M=M.numpy(), cfg=np.array([B, K, D, Zd, H, T], dtype=np.int64), clip=np.array(clip),
+              X_seq=np.stack([r["X"].numpy() for r in ref_out]), Z_seq=np.stack([r["Z"].numpy() for r in ref_out]))
+    np.savez_compressed(os.path.join(GOLDEN, f"{name}.npz"), **fx)
+    print(f"[ok] {name}")
 
 
 def case_lair_sampler(ns, name, *, B, K, R, D, Zd, H, seed, T, n_final=None, freq=1):
@@ -286,6 +326,17 @@ def main():
                nkpc=4, cluster=5, R=5)
     case_acmwg(ns, "acmwg_pg_warmup", B=4, K=3, D=7, Zd=3, H=64, seed=808, warmup="pseudo_gibbs", W=3, T=10, p=0.05)
     case_acmwg(ns, "acmwg_nowarmup_noprior", B=4, K=2, D=6, Zd=3, H=64, seed=909, warmup="none", W=0, T=8, p=0.0)
+    case_acmwg(ns, "acmwg_ablation_mwg_target", B=4, K=3, D=7, Zd=3, H=64, seed=919, warmup="none", W=0, T=10, p=0.1,
+               ablation=True)
+    case_acmwg(ns, "acmwg_ablation_pg_warmup", B=3, K=2, D=6, Zd=3, H=64, seed=929, warmup="pseudo_gibbs", W=2, T=8,
+               p=0.1, ablation=True)
+    case_acmwg(ns, "mwg_pg_warmup_clip", B=4, K=3, D=7, Zd=3, H=64, seed=939, warmup="pseudo_gibbs", W=3, T=10, p=0.0,
+               plain_mwg=True, clip=True)
+    case_acmwg(ns, "mwg_nowarmup", B=4, K=2, D=6, Zd=3, H=64, seed=949, warmup="none", W=0, T=10, p=0.0, plain_mwg=True)
+    case_acmwg(ns, "mwg_irwg_warmup", B=3, K=5, D=9, Zd=4, H=64, seed=959, warmup="irwg", W=2, T=8, p=0.0,
+               nkpc=4, cluster=5, R=5, plain_mwg=True)
+    case_pseudo_gibbs(ns, "pseudo_gibbs_clip", B=4, K=3, D=7, Zd=3, H=64, seed=969, T=6, clip=True)
+    case_pseudo_gibbs(ns, "pseudo_gibbs_noclip", B=3, K=2, D=6, Zd=3, H=64, seed=979, T=5, clip=False)
     case_lair_sampler(ns, "lair_sampler_final", B=4, K=3, R=1, D=8, Zd=4, H=64, seed=111, T=5)
     case_lair_sampler(ns, "lair_sampler_final_n5", B=3, K=4, R=1, D=8, Zd=4, H=64, seed=222, T=4, n_final=5)
 

@@ -536,8 +536,11 @@ class RestrictedHistory:
 
 def acmwg_step(enc, dec, state, M, hist_X, draws, *, prior_mixture_probability,
                latent_dist="normal_with_eps", gen_dist="normal_with_eps",
-               encoder=None, decoder=None):
-    """One AC-MWG step (test_step_vae_sampling.py:1671-1755).
+               encoder=None, decoder=None, joint_target_new=False, joint_target_old=False):
+    """One AC-MWG step (test_step_vae_sampling.py:1671-1755).  The plain Metropolis-within-Gibbs
+    step (:1221-1269) is the same arithmetic with ``hist_X`` = the current imputations, no prior
+    mixture, and both log-likelihoods summed over all dimensions (``joint_target_new/old``);
+    AC-MWG's ``ablation_use_mwg_target`` sets ``joint_target_new`` only (:1722-1725 vs :1755).
 
     state: dict X[B,K,D], Z_old[B,K,Zd], mis_params_old[B,K,P], Z_old_prior_logprob[B,K],
     X_old_logprob[B,K].  hist_X[B,K,D] is the historical imputation the proposal conditions
@@ -565,7 +568,8 @@ def acmwg_step(enc, dec, state, M, hist_X, draws, *, prior_mixture_probability,
         zo_q = torch.logsumexp(torch.stack([zo_q + lq, zo_p + lp]), dim=0)
     zn_prior = std_normal_log_prob(Z_new).sum(-1)
     mis_params = decoder(Z_new)
-    x_new_lp = (gen_log_prob(X, mis_params, gen_dist) * M).sum(-1)
+    x_new_lp = gen_log_prob(X, mis_params, gen_dist)
+    x_new_lp = (x_new_lp if joint_target_new else x_new_lp * M).sum(-1)
     log_accept = (x_new_lp + zn_prior) - (state["X_old_logprob"] + state["Z_old_prior_logprob"]) \
         + (zo_q - zn_q)
     accepted = draws["u_accept"] < torch.exp(log_accept)
@@ -575,7 +579,8 @@ def acmwg_step(enc, dec, state, M, hist_X, draws, *, prior_mixture_probability,
     mp_upd = state["mis_params_old"] * na.unsqueeze(-1) + mis_params * accepted.unsqueeze(-1)
     X_m = gen_sample(mp_upd, gen_dist, draws["eps_x"])
     X_new = X * M + X_m * (~M)
-    x_old_lp = (gen_log_prob(X_new, mp_upd, gen_dist) * M).sum(-1)
+    x_old_lp = gen_log_prob(X_new, mp_upd, gen_dist)
+    x_old_lp = (x_old_lp if joint_target_old else x_old_lp * M).sum(-1)
     new_state = dict(X=X_new, Z_old=Z_upd, mis_params_old=mp_upd, Z_old_prior_logprob=zp_upd,
                      X_old_logprob=x_old_lp)
     out.update(dict(state=new_state, accepted=accepted, log_accept=log_accept, Z_new=Z_new,

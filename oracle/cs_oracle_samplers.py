@@ -7,6 +7,8 @@ Restates the control flow of
     (irwg/sampling/test_step_vae_sampling.py:1853-1977, 1979-2045),
   * ``TestVAEAdaptiveCollapsedMetropolisWithinGibbs.sampler`` with the ``none``,
     ``pseudo_gibbs`` and ``irwg`` warm-ups (:1512-1768),
+  * ``TestVAEMetropolisWithinGibbs.sampler`` (:1090-1282) and ``TestVAEPseudoGibbs.sampler``
+    (:1023-1042),
   * the 'vae_samples' initial imputation (:279-287),
 with every random draw taken, in the reference's call order, from a *draw source*: either a
 recorded tape (parity against the reference / against the HIP engine) or a seeded generator
@@ -208,10 +210,16 @@ def acmwg_sampler(enc, dec, X, M, src, *, num_pseudo_warmup_iterations, num_mwg_
                   glr_cluster_size=None, num_prior_replenish_proposals=0, num_imp_samples=1,
                   weighting_scheme="dmis_within_groups", resampling_scheme="glr",
                   resampling_method="multinomial", enqueue_allwarmup_samples_to_history=False,
-                  latent_dist="normal_with_eps", gen_dist="normal_with_eps"):
+                  latent_dist="normal_with_eps", gen_dist="normal_with_eps", ablation_use_mwg_target=False,
+                  plain_mwg=False, clip_imputations_during_pg_warmup=False):
     """Generator over AC-MWG iterations (warm-up iterations included), yielding
     {'X','Z' (absent during the irwg warm-up),'acceptance'} like the reference; MWG steps also
-    carry 'accepted', 'log_accept' and 'slots' for the parity tests."""
+    carry 'accepted', 'log_accept' and 'slots' for the parity tests.
+
+    ``plain_mwg`` restates TestVAEMetropolisWithinGibbs.sampler instead (:1090-1282): same
+    warm-ups, no history and no prior mixture, the proposal conditions on the current
+    imputations and the target is the joint of latents and missing values (log-likelihoods over
+    all dimensions)."""
     B, K, D = X.shape
     Zd = O.net_input_dim(dec)
     W = num_pseudo_warmup_iterations
@@ -220,6 +228,13 @@ def acmwg_sampler(enc, dec, X, M, src, *, num_pseudo_warmup_iterations, num_mwg_
     else:
         max_it = W + num_mwg_iterations
     hist = O.RestrictedHistory(max_it, X.shape, X.dtype)
+    if plain_mwg:
+        assert prior_mixture_probability == 0.0
+    clip_min = clip_max = None
+    if clip_imputations_during_pg_warmup:  # clipping_mode 'batch_data' (:1097-1102)
+        Xt = X[:, 0].clone() * M.squeeze(1)
+        clip_max = torch.max(Xt, dim=0)[0] * 2
+        clip_min = torch.min(Xt, dim=0)[0] * 2
 
     def propose_from(Xc):
         q_loc, q_scale = O.split_loc_scale(O.resfc_forward(enc, Xc), latent_dist)
@@ -237,6 +252,9 @@ def acmwg_sampler(enc, dec, X, M, src, *, num_pseudo_warmup_iterations, num_mwg_
             Z_new = q_loc + q_scale * draws["eps_z"]
             mis_params = O.resfc_forward(dec, Z_new)
             X_m = O.gen_sample(mis_params, gen_dist, draws["eps_x"])
+            if clip_imputations_during_pg_warmup:
+                X_m = torch.min(torch.max(X_m, clip_min), clip_max)
+                X_m = torch.where(~X_m.isfinite(), X, X_m)
             X = X * M + X_m * (~M)
             if enqueue_allwarmup_samples_to_history or t == W - 1:
                 hist.enqueue(X)
@@ -273,9 +291,20 @@ def acmwg_sampler(enc, dec, X, M, src, *, num_pseudo_warmup_iterations, num_mwg_
     else:
         raise NotImplementedError(warmup_method)
 
+    x_lp = O.gen_log_prob(X, mis_params, gen_dist)
     state = dict(X=X, Z_old=Z_new, mis_params_old=mis_params,
                  Z_old_prior_logprob=O.std_normal_log_prob(Z_new).sum(-1),
-                 X_old_logprob=(O.gen_log_prob(X, mis_params, gen_dist) * M).sum(-1))
+                 X_old_logprob=(x_lp if (plain_mwg or ablation_use_mwg_target) else x_lp * M).sum(-1))  # :1216-1217, :1657-1660
+    if plain_mwg:
+        for t in range(num_mwg_iterations):
+            draws = {"eps_z": src.normal(B, K, Zd), "u_accept": src.uniform(B, K),
+                     "eps_x": src.uniform(B, K, D) if gen_dist == "bern" else src.normal(B, K, D)}
+            o = O.acmwg_step(enc, dec, state, M, state["X"], draws, prior_mixture_probability=0.0,
+                             latent_dist=latent_dist, gen_dist=gen_dist, joint_target_new=True, joint_target_old=True)
+            state = o["state"]
+            yield {"X": state["X"], "Z": state["Z_old"], "acceptance": o["acceptance"], "accepted": o["accepted"],
+                   "log_accept": o["log_accept"]}
+        return
     hist.update_available(torch.ones(B, K, dtype=torch.bool))
     for t in range(num_mwg_iterations):
         bounds = hist.draw_bounds()
@@ -292,9 +321,28 @@ def acmwg_sampler(enc, dec, X, M, src, *, num_pseudo_warmup_iterations, num_mwg_
         draws["u_accept"] = src.uniform(B, K)
         draws["eps_x"] = src.uniform(B, K, D) if gen_dist == "bern" else src.normal(B, K, D)
         o = O.acmwg_step(enc, dec, state, M, hist_X, draws, prior_mixture_probability=prior_mixture_probability,
-                         latent_dist=latent_dist, gen_dist=gen_dist)
+                         latent_dist=latent_dist, gen_dist=gen_dist, joint_target_new=ablation_use_mwg_target)
         hist.update_available(o["accepted"])
         state = o["state"]
         hist.enqueue(state["X"])
         yield {"X": state["X"], "Z": state["Z_old"], "acceptance": o["acceptance"], "accepted": o["accepted"],
                "log_accept": o["log_accept"], "slots": slots, "r": r}
+
+
+def pseudo_gibbs_sampler(enc, dec, X, M, src, *, num_iterations, clip_imputations=False,
+                         latent_dist="normal_with_eps", gen_dist="normal_with_eps"):
+    """TestVAEPseudoGibbs.sampler (test_step_vae_sampling.py:1023-1042), clipping_mode
+    'batch_data'.  Yields {'X','Z'}."""
+    B, K, D = X.shape
+    Zd = O.net_input_dim(dec)
+    clip_min = clip_max = None
+    if clip_imputations:
+        Xt = X[:, 0].clone() * M.squeeze(1)
+        clip_max = torch.max(Xt, dim=0)[0] * 2
+        clip_min = torch.min(Xt, dim=0)[0] * 2
+    for t in range(num_iterations):
+        draws = {"eps_z": src.normal(B, K, Zd),
+                 "eps_x": src.uniform(B, K, D) if gen_dist == "bern" else src.normal(B, K, D)}
+        X, Z = O.pseudo_gibbs_iteration(enc, dec, X, M, draws, latent_dist=latent_dist, gen_dist=gen_dist,
+                                        clip_min=clip_min, clip_max=clip_max)
+        yield {"X": X, "Z": Z}

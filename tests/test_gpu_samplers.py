@@ -24,19 +24,25 @@ def tape_source(fx):
     return TapeSource(tape_from_npz_dict(fx))
 
 
-@pytest.mark.parametrize("name", ["acmwg_irwg_warmup", "acmwg_pg_warmup", "acmwg_nowarmup_noprior"])
+@pytest.mark.parametrize("name", ["acmwg_irwg_warmup", "acmwg_pg_warmup", "acmwg_nowarmup_noprior",
+                                  "acmwg_ablation_mwg_target", "acmwg_ablation_pg_warmup",
+                                  "mwg_pg_warmup_clip", "mwg_nowarmup", "mwg_irwg_warmup"])
 def test_acmwg_sampler_matches_reference_golden(name):
-    from vae_conditional_sampling_amd.sampling.test_step_vae_sampling import \
-        TestVAEAdaptiveCollapsedMetropolisWithinGibbs as Sampler
+    """AC-MWG (incl. its ablation_use_mwg_target) and the plain Metropolis-within-Gibbs class."""
+    from vae_conditional_sampling_amd.sampling import test_step_vae_sampling as TS
     fx = load_golden(name)
     B, K, D, Zd, H, W, T, nkpc, cluster, R = [int(v) for v in fx["cfg"]]
     warmup = str(fx["warmup"])
     model = make_model(weights_from_fixture(fx, "enc"), weights_from_fixture(fx, "dec"))
-    kw = dict(num_pseudo_warmup_iterations=W, num_mwg_iterations=T, prior_mixture_probability=float(fx["p"]),
-              warmup_method=warmup, num_copies=K, **BASE_KW)
+    kw = dict(num_pseudo_warmup_iterations=W, num_mwg_iterations=T, warmup_method=warmup, num_copies=K,
+              clip_imputations_during_pg_warmup=bool(fx["clip"]), **BASE_KW)
     if warmup == "irwg":
         kw.update(num_k_per_cluster=nkpc, glr_cluster_size=cluster, num_prior_replenish_proposals=R)
-    s = Sampler(**kw)
+    if bool(fx["plain_mwg"]):
+        s = TS.TestVAEMetropolisWithinGibbs(**kw)
+    else:
+        s = TS.TestVAEAdaptiveCollapsedMetropolisWithinGibbs(prior_mixture_probability=float(fx["p"]),
+                                                             ablation_use_mwg_target=bool(fx["ablation"]), **kw)
     s.set_model(model)
     s.on_test_start()
     s.draw_source = tape_source(fx)
@@ -50,12 +56,31 @@ def test_acmwg_sampler_matches_reference_golden(name):
     mwg = [o for o in outs if "_accepted" in o]
     acc = np.stack([o["_accepted"].cpu().numpy().astype(bool) for o in mwg])
     assert np.array_equal(acc, fx["accepted"]), "accept decisions differ"
-    slots = np.stack([o["_slots"].cpu().numpy() for o in mwg])
-    assert np.array_equal(slots, fx["slots"]), "history slots differ"
+    if "slots" in fx:
+        slots = np.stack([o["_slots"].cpu().numpy() for o in mwg])
+        assert np.array_equal(slots, fx["slots"]), "history slots differ"
     for t, o in enumerate(outs):
         assert_close(o["X"], fx["X_seq"][t], f"X[{t}]")
         assert abs(float(o["acceptance"]) - float(fx["acceptance"][t])) < 1e-6
     assert_close(outs[-1]["Z"], fx["Z_last"], "Z")
+
+
+@pytest.mark.parametrize("name", ["pseudo_gibbs_clip", "pseudo_gibbs_noclip"])
+def test_pseudo_gibbs_sampler_matches_reference_golden(name):
+    from vae_conditional_sampling_amd.sampling.test_step_vae_sampling import TestVAEPseudoGibbs as Sampler
+    fx = load_golden(name)
+    B, K, D, Zd, H, T = [int(v) for v in fx["cfg"]]
+    model = make_model(weights_from_fixture(fx, "enc"), weights_from_fixture(fx, "dec"))
+    s = Sampler(num_iterations=T, clip_imputations=bool(fx["clip"]), num_copies=K, **BASE_KW)
+    s.set_model(model)
+    s.on_test_start()
+    s.draw_source = tape_source(fx)
+    outs = [{k: v.clone() for k, v in o.items()}
+            for o in s.sampler(torch.from_numpy(fx["X0"]).cuda(), torch.from_numpy(fx["M"]).cuda())]
+    assert len(outs) == T and s.draw_source.pos == len(s.draw_source.entries)
+    for t, o in enumerate(outs):
+        assert_close(o["X"], fx["X_seq"][t], f"X[{t}]")
+        assert_close(o["Z"], fx["Z_seq"][t], f"Z[{t}]")
 
 
 @pytest.mark.parametrize("name", ["lair_sampler_final", "lair_sampler_final_n5"])

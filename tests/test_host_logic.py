@@ -84,7 +84,8 @@ def test_driver_config_and_data_module(tmp_path):
     tester = cls(**cfg["test_class"]["init_args"])
     assert tester.max_iterations == 3
     with pytest.raises(NotImplementedError):
-        driver.resolve_test_class("irwg.sampling.test_step_vae_sampling.TestVAEPseudoGibbs")
+        driver.resolve_test_class("irwg.sampling.test_step_vae_sampling.TestVAEMetropolisWithinGibbsMNAR")
+    assert driver.resolve_test_class("irwg.sampling.test_step_vae_sampling.TestVAEPseudoGibbs").__name__ == "TestVAEPseudoGibbs"
     dm = MissingDataModule(**cfg["data"])
     dm.setup("test")
     X, M, I = dm.test_data

@@ -42,7 +42,11 @@ def test_oracle_lair_iteration(name):
         X = o["X_new"]
 
 
-@pytest.mark.parametrize("name", ["acmwg_irwg_warmup", "acmwg_pg_warmup", "acmwg_nowarmup_noprior"])
+MWG_CASES = ["acmwg_irwg_warmup", "acmwg_pg_warmup", "acmwg_nowarmup_noprior", "acmwg_ablation_mwg_target",
+             "acmwg_ablation_pg_warmup", "mwg_pg_warmup_clip", "mwg_nowarmup", "mwg_irwg_warmup"]
+
+
+@pytest.mark.parametrize("name", MWG_CASES)
 def test_oracle_acmwg_sampler(name):
     fx = load_golden(name)
     B, K, D, Zd, H, W, T, nkpc, cluster, R = [int(v) for v in fx["cfg"]]
@@ -52,13 +56,30 @@ def test_oracle_acmwg_sampler(name):
                                 num_pseudo_warmup_iterations=W, num_mwg_iterations=T,
                                 prior_mixture_probability=float(fx["p"]), warmup_method=str(fx["warmup"]),
                                 num_k_per_cluster=nkpc or None, glr_cluster_size=cluster or None,
-                                num_prior_replenish_proposals=R))
+                                num_prior_replenish_proposals=R, plain_mwg=bool(fx["plain_mwg"]),
+                                ablation_use_mwg_target=bool(fx["ablation"]),
+                                clip_imputations_during_pg_warmup=bool(fx["clip"])))
     assert src.pos == len(src.entries)
     mwg = [o for o in outs if "accepted" in o]
     assert np.array_equal(np.stack([o["accepted"].numpy() for o in mwg]), fx["accepted"])
-    assert np.array_equal(np.stack([o["slots"].numpy() for o in mwg]), fx["slots"])
+    if "slots" in fx:
+        assert np.array_equal(np.stack([o["slots"].numpy() for o in mwg]), fx["slots"])
     for t, o in enumerate(outs):
         assert_close(o["X"], fx["X_seq"][t], f"X[{t}]")
+
+
+@pytest.mark.parametrize("name", ["pseudo_gibbs_clip", "pseudo_gibbs_noclip"])
+def test_oracle_pseudo_gibbs_sampler(name):
+    fx = load_golden(name)
+    B, K, D, Zd, H, T = [int(v) for v in fx["cfg"]]
+    enc, dec = weights_from_fixture(fx, "enc"), weights_from_fixture(fx, "dec")
+    src = S.TapeSource(S.tape_from_npz_dict(fx))
+    outs = list(S.pseudo_gibbs_sampler(enc, dec, torch.from_numpy(fx["X0"]), torch.from_numpy(fx["M"]), src,
+                                       num_iterations=T, clip_imputations=bool(fx["clip"])))
+    assert src.pos == len(src.entries) and len(outs) == T
+    for t, o in enumerate(outs):
+        assert_close(o["X"], fx["X_seq"][t], f"X[{t}]")
+        assert_close(o["Z"], fx["Z_seq"][t], f"Z[{t}]")
 
 
 @pytest.mark.parametrize("name", ["lair_sampler_final", "lair_sampler_final_n5"])

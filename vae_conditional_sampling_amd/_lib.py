@@ -23,6 +23,9 @@ STREAM_Z, STREAM_X, STREAM_URES, STREAM_URES2 = 1, 2, 3, 4
 STREAM_ZPRIOR, STREAM_UPRIOR, STREAM_UACC, STREAM_HIST = 5, 6, 7, 8
 STREAM_INIT_Z, STREAM_INIT_X, STREAM_UFINAL = 9, 10, 11
 
+# cs_acmwg_cfg.flags (include/csvae.h)
+CS_MWG_PROPOSE_FROM_CURRENT, CS_MWG_JOINT_TARGET_NEW, CS_MWG_JOINT_TARGET_OLD = 1, 2, 4
+
 
 class CsError(RuntimeError):
     pass
@@ -67,7 +70,7 @@ class cs_lair_bufs(C.Structure):
 class cs_acmwg_cfg(C.Structure):
     _fields_ = [("B", C.c_int32), ("K", C.c_int32), ("D", C.c_int32), ("Zd", C.c_int32),
                 ("latent_dist", C.c_int32), ("gen_dist", C.c_int32), ("hist_len", C.c_int32),
-                ("hist_tail", C.c_int32), ("hist_full", C.c_int32), ("reserved", C.c_int32),
+                ("hist_tail", C.c_int32), ("hist_full", C.c_int32), ("flags", C.c_int32),
                 ("prior_mixture_probability", C.c_double)]
 
 
@@ -119,6 +122,7 @@ def lib():
     L.cs_final_resample.argtypes = [vp, vp, i64, i64, i32, i32, vp, C.POINTER(cs_rng), i64, vp, vp, vp, vp]
     L.cs_stdnormal_logprob_rows.argtypes = [vp, i64, i32, vp, vp]
     L.cs_decode_params.argtypes = [vp, vp, i64, i32, vp, vp]
+    L.cs_gen_loglik_rows.argtypes = [vp, i32, vp, vp, i64, i32, i32, vp, vp]
     L.cs_debug_set_workspace_budget.argtypes = [i64]
     L.cs_imputation_errors.argtypes = [vp, vp, vp, i64, i32, i32, vp, vp, vp]
     L.cs_latent_wasserstein.argtypes = [vp, vp, i64, i32, i32, vp, vp]

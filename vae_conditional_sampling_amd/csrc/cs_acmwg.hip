@@ -13,6 +13,10 @@
 //             imputation, ring write, new log-likelihood                       (:1693-1755)
 // The ring [T,B,K,D] and the availability counters [B,K] live in HBM; the host only tracks the
 // tail slot and the "full" flag, which evolve deterministically.
+//
+// The same kernels serve the plain Metropolis-within-Gibbs sampler
+// (TestVAEMetropolisWithinGibbs.sampler, :1219-1282) through cfg.flags: the proposal conditions on
+// the current imputation (no history) and the log-likelihoods sum over all dimensions.
 #include "cs_mlp.h"
 
 #include <cstring>
@@ -35,21 +39,23 @@ __global__ void __launch_bounds__(256) cs_acmwg_prepare_kernel(const CsAcmwgArgs
   const int B = a.cfg.B, K = a.cfg.K, D = a.cfg.D, Zd = a.cfg.Zd;
   if (t >= (int64_t)B * K) return;
   const int64_t grow = a.rng.row_offset * K + t;  // global chain row
-  // uniform index among the available history entries (utils.py:219-237)
-  int64_t bound = a.b.avail[t];
-  if (bound < 1) bound = 1;
-  int64_t r;
-  if (a.b.r_hist) {
-    r = a.b.r_hist[t];
-  } else {
-    uint32_t x[4];
-    cs_philox_block(a.rng, CS_STREAM_HIST, grow, 0, x);
-    r = (int64_t)(((uint64_t)x[0] * (uint64_t)bound) >> 32);
+  if (!(a.cfg.flags & CS_MWG_PROPOSE_FROM_CURRENT)) {
+    // uniform index among the available history entries (utils.py:219-237)
+    int64_t bound = a.b.avail[t];
+    if (bound < 1) bound = 1;
+    int64_t r;
+    if (a.b.r_hist) {
+      r = a.b.r_hist[t];
+    } else {
+      uint32_t x[4];
+      cs_philox_block(a.rng, CS_STREAM_HIST, grow, 0, x);
+      r = (int64_t)(((uint64_t)x[0] * (uint64_t)bound) >> 32);
+    }
+    int64_t slot = r;
+    if (a.cfg.hist_full) slot = (r + a.cfg.hist_tail + 1) % a.cfg.hist_len;
+    a.b.slots[t] = slot;
+    a.b.in_off[t] = (slot * B * K + t) * D;
   }
-  int64_t slot = r;
-  if (a.cfg.hist_full) slot = (r + a.cfg.hist_tail + 1) % a.cfg.hist_len;
-  a.b.slots[t] = slot;
-  a.b.in_off[t] = (slot * B * K + t) * D;
   // prior-mixture mask and prior proposal (:1687-1691)
   uint8_t up = 0;
   if (a.cfg.prior_mixture_probability > 0.0) {
@@ -74,6 +80,8 @@ __global__ void __launch_bounds__(256) cs_acmwg_accept_kernel(const CsAcmwgArgs 
   const double p = a.cfg.prior_mixture_probability;
   const bool bern = a.cfg.gen_dist == CS_DIST_BERN;
   const int P = bern ? D : 2 * D;
+  const bool use_hist = !(a.cfg.flags & CS_MWG_PROPOSE_FROM_CURRENT);
+  const bool joint_old = (a.cfg.flags & CS_MWG_JOINT_TARGET_OLD) != 0;
 
   // proposal / prior log-densities of Z_new and Z_old (:1693-1715)
   float zn_q = 0.f, zo_q = 0.f, zn_p = 0.f, zo_p = 0.f;
@@ -113,20 +121,25 @@ __global__ void __launch_bounds__(256) cs_acmwg_accept_kernel(const CsAcmwgArgs 
     a.b.accepted[t] = acc;
     a.b.log_accept[t] = log_accept;
     a.b.z_old_prior_lp[t] = zold_prior * fn + zn_prior * fa;
-    // availability (utils.py:94-104): accepted chains see the whole history, then the enqueue
-    // of a full ring ages every chain by one
-    int64_t av = a.b.avail[t];
-    const int64_t len = a.cfg.hist_full ? a.cfg.hist_len : a.cfg.hist_tail + 1;
-    if (acc) av = len;
-    if (a.cfg.hist_full) av = av > 0 ? av - 1 : 0;
-    a.b.avail[t] = av;
+    if (use_hist) {
+      // availability (utils.py:94-104): accepted chains see the whole history, then the enqueue
+      // of a full ring ages every chain by one
+      int64_t av = a.b.avail[t];
+      const int64_t len = a.cfg.hist_full ? a.cfg.hist_len : a.cfg.hist_tail + 1;
+      if (acc) av = len;
+      if (a.cfg.hist_full) av = av > 0 ? av - 1 : 0;
+      a.b.avail[t] = av;
+    }
   }
   // multiply-blend of the chain state (:1739-1743)
   for (int d = lane; d < Zd; d += 64)
     a.b.Z_old[t * Zd + d] = a.b.Z_old[t * Zd + d] * fn + a.b.Z_new[t * Zd + d] * fa;
   // x_m ~ p(x_m | z), imputation, ring write, new masked log-likelihood (:1744-1755)
-  const int new_tail = (a.cfg.hist_tail + 1) % a.cfg.hist_len;
-  float* ring_row = a.b.ring + ((int64_t)new_tail * B * K + t) * D;
+  float* ring_row = nullptr;
+  if (use_hist) {
+    const int new_tail = (a.cfg.hist_tail + 1) % a.cfg.hist_len;
+    ring_row = a.b.ring + ((int64_t)new_tail * B * K + t) * D;
+  }
   float ll = 0.f;
   for (int d = lane; d < D; d += 64) {
     const float m = (float)a.b.M[b * D + d];
@@ -140,7 +153,7 @@ __global__ void __launch_bounds__(256) cs_acmwg_accept_kernel(const CsAcmwgArgs 
       const float xn = xo * m + xm * (1.0f - m);
       lpx = cs_bernoulli_logpmf(xn, l);
       a.b.X[t * D + d] = xn;
-      ring_row[d] = xn;
+      if (ring_row) ring_row[d] = xn;
     } else {
       const float mean = a.b.gen_old[t * P + d] * fn + a.b.gen_new[t * P + d] * fa;
       const float sc = a.b.gen_old[t * P + D + d] * fn + a.b.gen_new[t * P + D + d] * fa;
@@ -151,9 +164,9 @@ __global__ void __launch_bounds__(256) cs_acmwg_accept_kernel(const CsAcmwgArgs 
       const float xn = xo * m + xm * (1.0f - m);
       lpx = cs_normal_logpdf(xn, mean, sc);
       a.b.X[t * D + d] = xn;
-      ring_row[d] = xn;
+      if (ring_row) ring_row[d] = xn;
     }
-    ll += lpx * m;
+    ll += joint_old ? lpx : lpx * m;
   }
   ll = wsum(ll);
   if (lane == 0) a.b.x_old_lp[t] = ll;
@@ -168,6 +181,25 @@ __global__ void cs_rowsum_stdnormal_kernel(const float* Z, int64_t rows, int Zd,
   for (int d = lane; d < Zd; d += 64) s += cs_stdnormal_logpdf(Z[t * Zd + d]);
   s = wsum(s);
   if (lane == 0) out[t] = s;
+}
+
+// sum_d w_d log p(X[t,d] | gen[t]) per chain t = (b,k); w = M[b,:] or 1.  One wavefront per chain.
+__global__ void __launch_bounds__(256) cs_gen_loglik_kernel(const float* gen, int gen_dist, const float* X,
+                                                            const uint8_t* M, int64_t chains, int K, int D, float* out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t t = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (t >= chains) return;
+  const int64_t b = t / K;
+  const bool bern = gen_dist == CS_DIST_BERN;
+  const float* g = gen + t * (bern ? D : 2 * D);
+  float ll = 0.f;
+  for (int d = lane; d < D; d += 64) {
+    const float x = X[t * D + d];
+    const float lp = bern ? cs_bernoulli_logpmf(x, g[d]) : cs_normal_logpdf(x, g[d], g[D + d]);
+    ll += M ? lp * (float)M[b * D + d] : lp;
+  }
+  ll = wsum(ll);
+  if (lane == 0) out[t] = ll;
 }
 
 __global__ void cs_history_enqueue_kernel(float* ring_slot, const float* X, int64_t n, int64_t* avail, int64_t chains,
@@ -221,7 +253,8 @@ extern "C" int cs_acmwg_init_state(const cs_mlp_t* enc, const cs_mlp_t* dec, con
   d.net = dec->dev; d.mode = CS_MLP_DEC; d.rows = e.rows;
   fill_mlp_common(d, c);
   d.q = b->q; d.gen_dist = c->gen_dist; d.eps_z = b->eps_z; d.rng = cs_make_philox(rng);
-  d.Z = b->Z_old; d.gen = b->gen_old; d.gen_ll = b->x_old_lp; d.X = b->X; d.M = b->M;
+  d.Z = b->Z_old; d.gen = b->gen_old; d.gen_ll = b->x_old_lp; d.X = b->X;
+  d.M = (c->flags & CS_MWG_JOINT_TARGET_OLD) ? nullptr : b->M;
   if (int rc = cs_mlp_launch(d, (hipStream_t)stream)) return rc;
   const int64_t rows = e.rows;
   hipLaunchKernelGGL(cs_rowsum_stdnormal_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
@@ -233,11 +266,16 @@ extern "C" int cs_acmwg_init_state(const cs_mlp_t* enc, const cs_mlp_t* dec, con
 extern "C" int cs_acmwg_step(const cs_mlp_t* enc, const cs_mlp_t* dec, const cs_acmwg_cfg* c, const cs_acmwg_bufs* b,
                              const cs_rng* rng, void* stream) {
   if (int rc = check_acmwg(c, b)) return rc;
-  CS_REQUIRE(enc && dec && b->X && b->M && b->Z_old && b->gen_old && b->z_old_prior_lp && b->x_old_lp && b->ring &&
-                 b->avail && b->slots && b->in_off && b->use_prior && b->z_alt && b->q && b->Z_new && b->gen_new &&
-                 b->ll_new && b->accepted && b->log_accept,
+  CS_REQUIRE(enc && dec && b->X && b->M && b->Z_old && b->gen_old && b->z_old_prior_lp && b->x_old_lp && b->q &&
+                 b->Z_new && b->gen_new && b->ll_new && b->accepted && b->log_accept,
              "null argument");
-  CS_REQUIRE(c->hist_len >= 1 && c->hist_tail >= 0 && c->hist_tail < c->hist_len, "bad history state");
+  const bool use_hist = !(c->flags & CS_MWG_PROPOSE_FROM_CURRENT);
+  const bool mix = c->prior_mixture_probability > 0.0;
+  if (use_hist) {
+    CS_REQUIRE(b->ring && b->avail && b->slots && b->in_off, "null history argument");
+    CS_REQUIRE(c->hist_len >= 1 && c->hist_tail >= 0 && c->hist_tail < c->hist_len, "bad history state");
+  }
+  CS_REQUIRE(!(use_hist || mix) || (b->use_prior && b->z_alt), "null argument (use_prior / z_alt)");
   const bool bern = c->gen_dist == CS_DIST_BERN;
   CS_REQUIRE(enc->dev.in_dim == c->D && enc->dev.out_dim == 2 * c->Zd && enc->dev.split == 2,
              "encoder shape does not match the configuration");
@@ -247,12 +285,19 @@ extern "C" int cs_acmwg_step(const cs_mlp_t* enc, const cs_mlp_t* dec, const cs_
   CsAcmwgArgs a;
   a.cfg = *c; a.b = *b; a.rng = cs_make_philox(rng);
   const int64_t chains = (int64_t)c->B * c->K;
-  hipLaunchKernelGGL(cs_acmwg_prepare_kernel, dim3((unsigned)((chains + 255) / 256)), dim3(256), 0, st, a);
-  CS_HIP(hipGetLastError());
+  if (use_hist || mix) {
+    hipLaunchKernelGGL(cs_acmwg_prepare_kernel, dim3((unsigned)((chains + 255) / 256)), dim3(256), 0, st, a);
+    CS_HIP(hipGetLastError());
+  }
   CsMlpArgs e;
   std::memset(&e, 0, sizeof(e));
   e.net = enc->dev; e.mode = CS_MLP_ENC; e.rows = chains;
-  e.in = b->ring; e.in_off = b->in_off; e.q = b->q;
+  if (use_hist) {
+    e.in = b->ring; e.in_off = b->in_off;
+  } else {
+    e.in = b->X; e.in_stride = c->D;
+  }
+  e.q = b->q;
   fill_mlp_common(e, c);
   e.latent_dist = c->latent_dist;
   if (int rc = cs_mlp_launch(e, st)) return rc;
@@ -261,8 +306,11 @@ extern "C" int cs_acmwg_step(const cs_mlp_t* enc, const cs_mlp_t* dec, const cs_
   d.net = dec->dev; d.mode = CS_MLP_DEC; d.rows = chains;
   fill_mlp_common(d, c);
   d.q = b->q; d.gen_dist = c->gen_dist; d.eps_z = b->eps_z; d.rng = a.rng;
-  d.z_override = b->use_prior; d.z_alt = b->z_alt;
-  d.Z = b->Z_new; d.gen = b->gen_new; d.gen_ll = b->ll_new; d.X = b->X; d.M = b->M;
+  if (use_hist || mix) {
+    d.z_override = b->use_prior; d.z_alt = b->z_alt;
+  }
+  d.Z = b->Z_new; d.gen = b->gen_new; d.gen_ll = b->ll_new; d.X = b->X;
+  d.M = (c->flags & CS_MWG_JOINT_TARGET_NEW) ? nullptr : b->M;
   if (int rc = cs_mlp_launch(d, st)) return rc;
   hipLaunchKernelGGL(cs_acmwg_accept_kernel, dim3((unsigned)((chains + 3) / 4)), dim3(256), 0, st, a);
   CS_HIP(hipGetLastError());
@@ -285,6 +333,18 @@ extern "C" int cs_history_set_available(int64_t* avail, const uint8_t* mask, int
   if (chains == 0) return CS_OK;
   hipLaunchKernelGGL(cs_history_available_kernel, dim3((unsigned)((chains + 255) / 256)), dim3(256), 0,
                      (hipStream_t)stream, avail, mask, chains, len);
+  CS_HIP(hipGetLastError());
+  return CS_OK;
+}
+
+extern "C" int cs_gen_loglik_rows(const float* gen, int32_t gen_dist, const float* X, const uint8_t* M, int64_t B,
+                                  int32_t K, int32_t D, float* out, void* stream) {
+  CS_REQUIRE(gen && X && out && B >= 0 && K >= 1 && D >= 1, "bad argument");
+  CS_REQUIRE(gen_dist >= CS_DIST_NORMAL && gen_dist <= CS_DIST_BERN, "bad generator distribution");
+  const int64_t chains = B * K;
+  if (chains == 0) return CS_OK;
+  hipLaunchKernelGGL(cs_gen_loglik_kernel, dim3((unsigned)((chains + 3) / 4)), dim3(256), 0, (hipStream_t)stream, gen,
+                     gen_dist, X, M, chains, K, D, out);
   CS_HIP(hipGetLastError());
   return CS_OK;
 }

@@ -494,7 +494,7 @@ __global__ void __launch_bounds__(64) cs_dec_finish_kernel(const CsMlpArgs a, co
   const bool want_ll = a.gen_ll != nullptr;
   const int64_t xk = kp < a.K ? kp : 0;
   const float* xr = want_ll ? a.X + (b * a.K + xk) * D : nullptr;
-  const uint8_t* mr = want_ll ? a.M + b * D : nullptr;
+  const uint8_t* mr = want_ll && a.M ? a.M + b * D : nullptr;  // no mask: every dimension counts
   float ll = 0.0f;
   if (a.gen_dist == CS_DIST_BERN) {
     const float* pr = raw + r * D;
@@ -502,7 +502,7 @@ __global__ void __launch_bounds__(64) cs_dec_finish_kernel(const CsMlpArgs a, co
     for (int d = lane; d < D; d += 64) {
       const float l = pr[d];
       gr[d] = l;
-      if (want_ll) ll += cs_bernoulli_logpmf(xr[d], l) * (float)mr[d];
+      if (want_ll) ll += cs_bernoulli_logpmf(xr[d], l) * (mr ? (float)mr[d] : 1.0f);
     }
   } else {
     const float* pr = raw + r * 2 * D;
@@ -513,7 +513,7 @@ __global__ void __launch_bounds__(64) cs_dec_finish_kernel(const CsMlpArgs a, co
       const float sc = cs_softplus(pr[D + d]) + eps;
       gr[d] = mean;
       gr[D + d] = sc;
-      if (want_ll) ll += cs_normal_logpdf(xr[d], mean, sc) * (float)mr[d];
+      if (want_ll) ll += cs_normal_logpdf(xr[d], mean, sc) * (mr ? (float)mr[d] : 1.0f);
     }
   }
   if (want_ll) {

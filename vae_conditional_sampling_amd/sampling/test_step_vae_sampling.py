@@ -525,7 +525,278 @@ class TestVAELatentAdaptiveImportanceResampling(TestVAESamplerBase):
         return out
 
 
-class TestVAEAdaptiveCollapsedMetropolisWithinGibbs(TestVAESamplerBase):
+class TestVAEPseudoGibbs(TestVAESamplerBase):
+    """Pseudo-Gibbs sampling (test_step_vae_sampling.py:1002-1042)."""
+
+    def __init__(self,
+                 num_iterations: int,
+                 *args,
+                 clip_imputations: bool = False,
+                 clipping_mode: str = 'batch_data',
+                 **kwargs
+                 ):
+        super().__init__(*args, **kwargs)
+        self.save_hyperparameters()
+
+    @property
+    def max_iterations(self):
+        return self.hparams.num_iterations
+
+    def sampler(self, X, M):
+        hp = self.hparams
+        B, K, D = X.shape
+        bern = self.model.hparams.generator_distribution.name == "bern"
+        clip_min = clip_max = None
+        if hp.clip_imputations:
+            clip_max, clip_min = _clip_values(self, X, M, hp.clipping_mode)
+        X = X.clone().contiguous()
+        for t in range(hp.num_iterations):
+            draws = None
+            if self.draw_source is not None:
+                src = self.draw_source
+                draws = {"eps_z": src.normal(B, K, self.model.latent_dim),
+                         "eps_x": src.uniform(B, K, D) if bern else src.normal(B, K, D)}
+            # the reference calls the same function with and without clip values (:1037-1040); the
+            # non-finite safety applies in both cases
+            X, Z_imp = pseudo_gibbs_iteration(self.model, X, M, clip_min, clip_max, rng=self._rng(), draws=draws,
+                                              inplace=True)
+            self._next_iteration()
+            yield {'X': X, 'Z': Z_imp.clone()}
+
+
+def _clip_values(self, X, M, clipping_mode):
+    """(max, min) bounds of the pseudo-Gibbs clipping (test_step_vae_sampling.py:1024-1034,1097-1107)."""
+    if clipping_mode == 'batch_data':
+        X_temp = X[:, 0].clone()
+        X_temp *= M.squeeze(1)
+        return ((torch.max(X_temp, dim=0)[0] * 2).contiguous(), (torch.min(X_temp, dim=0)[0] * 2).contiguous())
+    if clipping_mode == 'dataset':
+        core = self.datamodule.test_data_core
+        return (torch.tensor(core.data_max * 2, device=X.device, dtype=torch.float32).contiguous(),
+                torch.tensor(core.data_min * 2, device=X.device, dtype=torch.float32).contiguous())
+    raise NotImplementedError(f'Invalid {clipping_mode=}')
+
+
+class _MetropolisWithinGibbsCommon(TestVAESamplerBase):
+    """Warm-up phases and chain-state set-up shared by the two Metropolis-within-Gibbs samplers
+    (TestVAEMetropolisWithinGibbs :1090-1217, TestVAEAdaptiveCollapsedMetropolisWithinGibbs
+    :1512-1662).  ``on_warmup_imputation(X, last)`` is called with every warm-up imputation in the
+    order the reference produces them (AC-MWG enqueues some of them to its history)."""
+
+    @property
+    def max_iterations(self):
+        if self.hparams.warmup_method != 'irwg':
+            return self.hparams.num_pseudo_warmup_iterations + self.hparams.num_mwg_iterations
+        return (self.hparams.num_pseudo_warmup_iterations * self.hparams.num_k_per_cluster) + self.hparams.num_mwg_iterations
+
+    def on_test_start(self):
+        super().on_test_start()
+        hp = self.hparams
+        if hp.var_proposal_temperature is not None or hp.var_proposal_anneal_type_to_prior is not None:
+            raise NotImplementedError("proposal tempering / annealing is not implemented")
+        if hp.warmup_method not in ('none', 'pseudo_gibbs', 'irwg'):
+            raise NotImplementedError(f'{hp.warmup_method=}')
+
+    def _lair_warmup_draws(self, B, Kw, R, D):
+        src = self.draw_source
+        if src is None:
+            return None
+        hp = self.hparams
+        I, Kp, Zd = hp.num_imp_samples, Kw + R, self.model.latent_dim
+        d = {"eps_z": src.normal(I, B, Kp, Zd)}
+        G = Kp // hp.glr_cluster_size if hp.resampling_scheme == 'glr' else 1
+        if hp.resampling_method == 'multinomial':
+            d["u_res"] = src.uniform64(B * G, Kp // G)
+        else:
+            d["u_res"] = src.uniform(B, 1) if hp.resampling_scheme == 'gr' else src.uniform(B, G, 1)
+        bern = self.model.hparams.generator_distribution.name == "bern"
+        d["eps_x"] = src.uniform(B, Kw, D) if bern else src.normal(B, Kw, D)
+        return d
+
+    def _pseudo_gibbs_warmup(self, X, M, M8, on_warmup_imputation):
+        """Generator over the pseudo-Gibbs warm-up steps (:1119-1155, :1548-1591); returns X."""
+        hp, src, model = self.hparams, self.draw_source, self.model
+        B, K, D = X.shape
+        Zd = model.latent_dim
+        bern = model.hparams.generator_distribution.name == "bern"
+        clip_max = clip_min = None
+        if hp.clip_imputations_during_pg_warmup:
+            clip_max, clip_min = _clip_values(self, X, M, hp.clipping_mode)
+        W = hp.num_pseudo_warmup_iterations
+        for t in range(W):
+            draws = None
+            if src is not None:
+                draws = {"eps_z": src.normal(B, K, Zd), "eps_x": src.uniform(B, K, D) if bern else src.normal(B, K, D)}
+            if hp.clip_imputations_during_pg_warmup:
+                X, Z_new = pseudo_gibbs_iteration(model, X, M, clip_min, clip_max, rng=self._rng(), draws=draws,
+                                                  inplace=True)
+            else:
+                X, Z_new = self._pg_step_noclip(X, M, M8, draws)
+            self._next_iteration()
+            on_warmup_imputation(X, t == W - 1)
+            yield {'X': X, 'Z': Z_new.clone(), 'acceptance': 1.}
+        return X
+
+    def _irwg_warmup(self, X, M, on_warmup_imputation):
+        """Generator over the LAIR warm-up (:1156-1197, :1592-1636); returns the K chains' X."""
+        hp, model = self.hparams, self.model
+        B, K, D = X.shape
+        c, R = hp.glr_cluster_size, hp.num_prior_replenish_proposals
+        Kw = K * hp.num_k_per_cluster
+        X_w = X[:, :1].expand(B, Kw, D).contiguous()
+        X_w = self.basic_imputation(X_w, M)
+        W = hp.num_pseudo_warmup_iterations
+        for t in range(W):
+            ret = importance_resampling_gibbs_iteration(
+                model, X_w, M, hp.num_imp_samples, glr_cluster_size=c, weighting=hp.weighting_scheme,
+                resampling_method=hp.resampling_method, resampling_scheme=hp.resampling_scheme,
+                num_prior_replenish_proposals=R, rng=self._rng(), draws=self._lair_warmup_draws(B, Kw, R, D),
+                inplace=True)
+            self._next_iteration()
+            X_w = ret[0]
+            # 'b (c k) -> b k c' (:1611), padded to K chains by repeating the first ones (:1613-1615)
+            X_temp = X_w.reshape(B, c, Kw // c, D).permute(0, 2, 1, 3).contiguous()
+            if R > 0:
+                needed = K - X_temp.shape[1]
+                X_temp = torch.cat([X_temp, X_temp[:, :needed]], dim=1)
+            for i in range(hp.num_k_per_cluster):
+                X_temp_i = X_temp[:, :, i].contiguous()
+                on_warmup_imputation(X_temp_i, t == W - 1)
+                yield {'X': X_temp_i, 'acceptance': 1.0}
+            if R > 0 and t == W - 1:
+                X_w = X_temp.permute(0, 2, 1, 3).reshape(B, c * X_temp.shape[1], D)
+        return X_w.reshape(B, c, X_w.shape[1] // c, D).permute(0, 2, 1, 3)[:, :, 0].contiguous()
+
+    def _state_after_pseudo_gibbs(self, st, X, M8, joint):
+        """Chain state = the last warm-up step's Z and generator parameters (:1214-1217,
+        :1653-1660): its buffers are still in the LAIR workspace of that step."""
+        model = self.model
+        B, K, D = X.shape
+        if self.hparams.num_pseudo_warmup_iterations < 1:
+            raise ValueError("pseudo_gibbs warm-up needs at least one iteration")
+        ws = engine.lair_workspace(model, B, K, 0, 1, X.device)
+        st["Z_old"].copy_(ws.Z[0])
+        st["gen_old"].copy_(ws.gen[0])
+        L, stream = _lib.lib(), _lib.current_stream()
+        _, gen_dist = model.engine_dists()
+        # log-likelihood of the *new* imputations under those parameters; with the observed-only sum
+        # this equals the value the step's decoder launch computed, but one rule covers both targets
+        _lib.check(L.cs_gen_loglik_rows(_lib.ptr(st["gen_old"]), gen_dist, _lib.ptr(X), None if joint else _lib.ptr(M8),
+                                        B, K, D, _lib.ptr(st["x_old_lp"]), stream))
+        _lib.check(L.cs_stdnormal_logprob_rows(_lib.ptr(st["Z_old"]), B * K, model.latent_dim,
+                                               _lib.ptr(st["z_old_prior_lp"]), stream))
+
+    def _pg_step_noclip(self, X, M, M8, draws):
+        """Pseudo-Gibbs warm-up step without the clipping / non-finite safety (:1553-1580)."""
+        import ctypes as C
+        B, K, D = X.shape
+        model = self.model
+        ws = engine.lair_workspace(model, B, K, 0, 1, X.device)
+        cfg = engine.lair_cfg(model, ws, weighting="smis", scheme="gr", method="multinomial", cluster_size=0,
+                              weight_alpha=None)
+        eps_z = draws["eps_z"].to(X.device, torch.float32).contiguous() if draws else None
+        bufs = _lib.make_bufs(X=X, M=M8, eps_z=eps_z, q=ws.q, Z=ws.Z, gen=ws.gen, gen_ll=ws.gen_ll)
+        rng = self._rng()
+        L = _lib.lib()
+        stq = _lib.current_stream()
+        _lib.check(L.cs_lair_encode(model.var_latent_network.packed().handle, C.byref(cfg), C.byref(bufs), stq))
+        _lib.check(L.cs_lair_decode(model.generator_network.packed().handle, C.byref(cfg), C.byref(bufs), C.byref(rng), stq))
+        engine.sample_impute(model, ws.gen, X, M8, K, eps=draws["eps_x"] if draws else None, rng=rng,
+                             stream_id=_lib.STREAM_X)
+        return X, ws.Z[0]
+
+    def _chain_buffers(self, B, K, D, Zd, P, dev):
+        f = dict(device=dev, dtype=torch.float32)
+        st = dict(Z_old=torch.empty(B, K, Zd, **f), gen_old=torch.empty(B, K, P, **f),
+                  z_old_prior_lp=torch.empty(B, K, **f), x_old_lp=torch.empty(B, K, **f))
+        wk = dict(q=torch.empty(B, K, 2, Zd, **f), Z_new=torch.empty(B, K, Zd, **f), gen_new=torch.empty(B, K, P, **f),
+                  ll_new=torch.empty(B, K, **f), accepted=torch.empty(B, K, device=dev, dtype=torch.uint8),
+                  log_accept=torch.empty(B, K, **f))
+        return st, wk
+
+
+class TestVAEMetropolisWithinGibbs(_MetropolisWithinGibbsCommon):
+    """Metropolis-within-Gibbs sampling (Mattei & Frellsen 2018) targeting the joint p(z, x_m | x_o)
+    (test_step_vae_sampling.py:1045-1282)."""
+
+    def __init__(self,
+                 num_pseudo_warmup_iterations: int,
+                 num_mwg_iterations: int,
+                 *args,
+                 clip_imputations_during_pg_warmup: bool = False,
+                 clipping_mode: str = 'batch_data',
+
+                 var_proposal_temperature: float = None,
+                 var_proposal_anneal_type_to_prior: str = None,
+                 warmup_method: str = 'pseudo_gibbs',
+
+                 # IRWG warmup
+                 num_k_per_cluster: int = None,
+                 num_imp_samples: int = 1,
+                 weighting_scheme: str = 'dmis_within_groups',
+                 resampling_scheme: str = 'glr',
+                 resampling_method: str = 'multinomial',
+                 glr_cluster_size: int = None,
+                 num_prior_replenish_proposals: int = 0,
+
+                 **kwargs
+                 ):
+        super().__init__(*args, **kwargs)
+        self.save_hyperparameters()
+        if self.hparams.warmup_method == 'irwg':
+            assert (self.hparams.num_k_per_cluster
+                    + self.hparams.num_prior_replenish_proposals / self.hparams.glr_cluster_size) == self.hparams.glr_cluster_size
+
+    def sampler(self, X, M):
+        import ctypes as C
+        hp, model, src = self.hparams, self.model, self.draw_source
+        B, K, D = X.shape
+        Zd = model.latent_dim
+        dev = X.device
+        latent, gen_dist = model.engine_dists()
+        bern = gen_dist == _lib.CS_DIST["bern"]
+        P = model.generator_network.output_dim
+        M8 = engine.mask_u8(M)
+        X = X.clone().contiguous()
+        nothing = lambda X, last: None
+
+        if hp.warmup_method == 'pseudo_gibbs':
+            X = yield from self._pseudo_gibbs_warmup(X, M, M8, nothing)
+        elif hp.warmup_method == 'irwg':
+            X = yield from self._irwg_warmup(X, M, nothing)
+
+        st, wk = self._chain_buffers(B, K, D, Zd, P, dev)
+        L = _lib.lib()
+        h_enc = model.var_latent_network.packed().handle
+        h_dec = model.generator_network.packed().handle
+        stream = _lib.current_stream()
+        flags = _lib.CS_MWG_PROPOSE_FROM_CURRENT | _lib.CS_MWG_JOINT_TARGET_NEW | _lib.CS_MWG_JOINT_TARGET_OLD
+        cfg = _lib.cs_acmwg_cfg(B, K, D, Zd, latent, gen_dist, 1, 0, 0, flags, 0.0)
+
+        if hp.warmup_method == 'pseudo_gibbs':
+            self._state_after_pseudo_gibbs(st, X, M8, joint=True)
+        else:  # 'none' / 'irwg': one proposal from the current imputations (:1110-1118, :1200-1208)
+            eps = src.normal(B, K, Zd).to(dev).contiguous() if src is not None else None
+            bufs = _lib.make_acmwg_bufs(X=X, M=M8, eps_z=eps, q=wk["q"], **st)
+            rng = self._rng()
+            _lib.check(L.cs_acmwg_init_state(h_enc, h_dec, C.byref(cfg), C.byref(bufs), C.byref(rng), stream))
+            self._next_iteration()
+
+        for t in range(hp.num_mwg_iterations):
+            d = {}
+            if src is not None:
+                d["eps_z"] = src.normal(B, K, Zd).to(dev).contiguous()
+                d["u_accept"] = src.uniform(B, K).to(dev).contiguous()
+                d["eps_x"] = (src.uniform(B, K, D) if bern else src.normal(B, K, D)).to(dev).contiguous()
+            bufs = _lib.make_acmwg_bufs(X=X, M=M8, **st, **wk, **d)
+            rng = self._rng()
+            _lib.check(L.cs_acmwg_step(h_enc, h_dec, C.byref(cfg), C.byref(bufs), C.byref(rng), stream))
+            self._next_iteration()
+            yield {'X': X, 'Z': st["Z_old"], 'acceptance': wk["accepted"].float().mean(),
+                   '_accepted': wk["accepted"], '_log_accept': wk["log_accept"]}
+
+
+class TestVAEAdaptiveCollapsedMetropolisWithinGibbs(_MetropolisWithinGibbsCommon):
     """Metropolis-within-Gibbs sampling with marginalised missing values, called AC-MWG
     (adaptive collapsed-Metropolis-within-Gibbs) in the paper."""
 
@@ -561,38 +832,6 @@ class TestVAEAdaptiveCollapsedMetropolisWithinGibbs(TestVAESamplerBase):
             assert (self.hparams.num_k_per_cluster
                     + self.hparams.num_prior_replenish_proposals / self.hparams.glr_cluster_size) == self.hparams.glr_cluster_size
 
-    @property
-    def max_iterations(self):
-        if self.hparams.warmup_method != 'irwg':
-            return self.hparams.num_pseudo_warmup_iterations + self.hparams.num_mwg_iterations
-        return (self.hparams.num_pseudo_warmup_iterations * self.hparams.num_k_per_cluster) + self.hparams.num_mwg_iterations
-
-    def on_test_start(self):
-        super().on_test_start()
-        hp = self.hparams
-        if hp.ablation_use_mwg_target:
-            raise NotImplementedError("ablation_use_mwg_target is not implemented")
-        if hp.var_proposal_temperature is not None or hp.var_proposal_anneal_type_to_prior is not None:
-            raise NotImplementedError("proposal tempering / annealing is not implemented")
-        if hp.warmup_method not in ('none', 'pseudo_gibbs', 'irwg'):
-            raise NotImplementedError(f'{hp.warmup_method=}')
-
-    def _lair_warmup_draws(self, B, Kw, R, D):
-        src = self.draw_source
-        if src is None:
-            return None
-        hp = self.hparams
-        I, Kp, Zd = hp.num_imp_samples, Kw + R, self.model.latent_dim
-        d = {"eps_z": src.normal(I, B, Kp, Zd)}
-        G = Kp // hp.glr_cluster_size if hp.resampling_scheme == 'glr' else 1
-        if hp.resampling_method == 'multinomial':
-            d["u_res"] = src.uniform64(B * G, Kp // G)
-        else:
-            d["u_res"] = src.uniform(B, 1) if hp.resampling_scheme == 'gr' else src.uniform(B, G, 1)
-        bern = self.model.hparams.generator_distribution.name == "bern"
-        d["eps_x"] = src.uniform(B, Kw, D) if bern else src.normal(B, Kw, D)
-        return d
-
     def sampler(self, X, M):
         import ctypes as C
         hp = self.hparams
@@ -607,109 +846,52 @@ class TestVAEAdaptiveCollapsedMetropolisWithinGibbs(TestVAESamplerBase):
         M8 = engine.mask_u8(M)
         X = X.clone().contiguous()
 
-        clip_values_max, clip_values_min = None, None
-        if hp.clip_imputations_during_pg_warmup:
-            if hp.clipping_mode == 'batch_data':
-                X_temp = X[:, 0].clone()
-                X_temp *= M.squeeze(1)
-                clip_values_max = (torch.max(X_temp, dim=0)[0] * 2).contiguous()
-                clip_values_min = (torch.min(X_temp, dim=0)[0] * 2).contiguous()
-            elif hp.clipping_mode == 'dataset':
-                clip_values_max = torch.tensor(self.datamodule.test_data_core.data_max * 2, device=dev,
-                                               dtype=torch.float32).contiguous()
-                clip_values_min = torch.tensor(self.datamodule.test_data_core.data_min * 2, device=dev,
-                                               dtype=torch.float32).contiguous()
-            else:
-                raise NotImplementedError(f'Invalid {hp.clipping_mode=}')
-
         bool_data = _check_if_bool(X)
         history = ImputationHistoryQueue_with_restrictedavailability(
             max_history_length=self.max_iterations, batch_shape=X.shape,
             dtype=X.dtype if not bool_data else torch.bool, device=dev)
         self.history = history
 
+        def enqueue(Xw, last):
+            if hp.enqueue_allwarmup_samples_to_history or last:
+                history.enqueue_batch(Xw)
+
         if hp.warmup_method == 'none':
             history.enqueue_batch(X)
         elif hp.warmup_method == 'pseudo_gibbs':
-            W = hp.num_pseudo_warmup_iterations
-            for t in range(W):
-                draws = None
-                if src is not None:
-                    draws = {"eps_z": src.normal(B, K, Zd), "eps_x": src.uniform(B, K, D) if bern else src.normal(B, K, D)}
-                if hp.clip_imputations_during_pg_warmup:
-                    X, Z_new = pseudo_gibbs_iteration(model, X, M, clip_values_min, clip_values_max, rng=self._rng(),
-                                                      draws=draws, inplace=True)
-                else:
-                    X, Z_new = self._pg_step_noclip(X, M, M8, draws)
-                self._next_iteration()
-                if hp.enqueue_allwarmup_samples_to_history or t == W - 1:
-                    history.enqueue_batch(X)
-                yield {'X': X, 'Z': Z_new.clone(), 'acceptance': 1.}
+            X = yield from self._pseudo_gibbs_warmup(X, M, M8, enqueue)
         elif hp.warmup_method == 'irwg':
-            c, R = hp.glr_cluster_size, hp.num_prior_replenish_proposals
-            Kw = K * hp.num_k_per_cluster
-            X_w = X[:, :1].expand(B, Kw, D).contiguous()
-            X_w = self.basic_imputation(X_w, M)
-            W = hp.num_pseudo_warmup_iterations
-            for t in range(W):
-                ret = importance_resampling_gibbs_iteration(
-                    model, X_w, M, hp.num_imp_samples, glr_cluster_size=c, weighting=hp.weighting_scheme,
-                    resampling_method=hp.resampling_method, resampling_scheme=hp.resampling_scheme,
-                    num_prior_replenish_proposals=R, rng=self._rng(), draws=self._lair_warmup_draws(B, Kw, R, D),
-                    inplace=True)
-                self._next_iteration()
-                X_w = ret[0]
-                # 'b (c k) -> b k c' (:1611), padded to K chains by repeating the first ones (:1613-1615)
-                X_temp = X_w.reshape(B, c, Kw // c, D).permute(0, 2, 1, 3).contiguous()
-                if R > 0:
-                    needed = K - X_temp.shape[1]
-                    X_temp = torch.cat([X_temp, X_temp[:, :needed]], dim=1)
-                for i in range(hp.num_k_per_cluster):
-                    X_temp_i = X_temp[:, :, i].contiguous()
-                    if hp.enqueue_allwarmup_samples_to_history or t == W - 1:
-                        history.enqueue_batch(X_temp_i)
-                    yield {'X': X_temp_i, 'acceptance': 1.0}
-                if R > 0 and t == W - 1:
-                    X_w = X_temp.permute(0, 2, 1, 3).reshape(B, c * X_temp.shape[1], D)
-            X = X_w.reshape(B, c, X_w.shape[1] // c, D).permute(0, 2, 1, 3)[:, :, 0].contiguous()
+            X = yield from self._irwg_warmup(X, M, enqueue)
 
         # ---- chain state after the warm-up (:1639-1662) ----
-        f = dict(device=dev, dtype=torch.float32)
-        st = dict(Z_old=torch.empty(B, K, Zd, **f), gen_old=torch.empty(B, K, P, **f),
-                  z_old_prior_lp=torch.empty(B, K, **f), x_old_lp=torch.empty(B, K, **f))
-        wk = dict(slots=torch.empty(B, K, device=dev, dtype=torch.int64),
+        st, wk = self._chain_buffers(B, K, D, Zd, P, dev)
+        wk.update(slots=torch.empty(B, K, device=dev, dtype=torch.int64),
                   in_off=torch.empty(B, K, device=dev, dtype=torch.int64),
-                  use_prior=torch.empty(B, K, device=dev, dtype=torch.uint8), z_alt=torch.empty(B, K, Zd, **f),
-                  q=torch.empty(B, K, 2, Zd, **f), Z_new=torch.empty(B, K, Zd, **f), gen_new=torch.empty(B, K, P, **f),
-                  ll_new=torch.empty(B, K, **f), accepted=torch.empty(B, K, device=dev, dtype=torch.uint8),
-                  log_accept=torch.empty(B, K, **f))
+                  use_prior=torch.empty(B, K, device=dev, dtype=torch.uint8),
+                  z_alt=torch.empty(B, K, Zd, device=dev, dtype=torch.float32))
         L = _lib.lib()
         h_enc = model.var_latent_network.packed().handle
         h_dec = model.generator_network.packed().handle
         stream = _lib.current_stream()
+        # the ablation scores the proposal on all dimensions of the current imputation, and so does
+        # the state right after the warm-up (:1657-1658), but every step then keeps the observed-only
+        # sum for the state it carries on (:1722-1725 vs :1755)
+        ablation = bool(hp.ablation_use_mwg_target)
+        flags = _lib.CS_MWG_JOINT_TARGET_NEW if ablation else 0
 
-        def cfg_now():
+        def cfg_now(flags=flags):
             return _lib.cs_acmwg_cfg(B, K, D, Zd, latent, gen_dist, history.max_history_length,
-                                     max(history.tail_idx, 0), int(history.full), 0,
+                                     max(history.tail_idx, 0), int(history.full), flags,
                                      float(hp.prior_mixture_probability))
 
         if hp.warmup_method == 'pseudo_gibbs':
-            if hp.num_pseudo_warmup_iterations < 1:
-                raise ValueError("pseudo_gibbs warm-up needs at least one iteration")
-            # the state is the last warm-up step's Z and generator parameters (:1653-1660); the
-            # masked log-likelihood only involves observed entries, which imputation never changes,
-            # so the value computed by that step's decoder launch is the one needed here
-            ws = engine.lair_workspace(model, B, K, 0, 1, dev)
-            st["Z_old"].copy_(ws.Z[0])
-            st["gen_old"].copy_(ws.gen[0])
-            st["x_old_lp"].copy_(ws.gen_ll[0])
-            _lib.check(L.cs_stdnormal_logprob_rows(_lib.ptr(st["Z_old"]), B * K, Zd, _lib.ptr(st["z_old_prior_lp"]),
-                                                   stream))
+            self._state_after_pseudo_gibbs(st, X, M8, joint=ablation)
         else:
             eps = src.normal(B, K, Zd).to(dev).contiguous() if src is not None else None
             bufs = _lib.make_acmwg_bufs(X=X, M=M8, eps_z=eps, q=wk["q"], **st)
             rng = self._rng()
-            _lib.check(L.cs_acmwg_init_state(h_enc, h_dec, C.byref(cfg_now()), C.byref(bufs), C.byref(rng), stream))
+            cfg0 = cfg_now(_lib.CS_MWG_JOINT_TARGET_OLD if ablation else 0)
+            _lib.check(L.cs_acmwg_init_state(h_enc, h_dec, C.byref(cfg0), C.byref(bufs), C.byref(rng), stream))
             self._next_iteration()
         history.update_available_timesteps(None)
 
@@ -736,23 +918,3 @@ class TestVAEAdaptiveCollapsedMetropolisWithinGibbs(TestVAESamplerBase):
             self._next_iteration()
             yield {'X': X, 'Z': st["Z_old"], 'acceptance': wk["accepted"].float().mean(),
                    '_accepted': wk["accepted"], '_slots': wk["slots"], '_log_accept': wk["log_accept"]}
-
-    # -- helpers --
-    def _pg_step_noclip(self, X, M, M8, draws):
-        """Pseudo-Gibbs warm-up step without the clipping / non-finite safety (:1553-1580)."""
-        import ctypes as C
-        B, K, D = X.shape
-        model = self.model
-        ws = engine.lair_workspace(model, B, K, 0, 1, X.device)
-        cfg = engine.lair_cfg(model, ws, weighting="smis", scheme="gr", method="multinomial", cluster_size=0,
-                              weight_alpha=None)
-        eps_z = draws["eps_z"].to(X.device, torch.float32).contiguous() if draws else None
-        bufs = _lib.make_bufs(X=X, M=M8, eps_z=eps_z, q=ws.q, Z=ws.Z, gen=ws.gen, gen_ll=ws.gen_ll)
-        rng = self._rng()
-        L = _lib.lib()
-        stq = _lib.current_stream()
-        _lib.check(L.cs_lair_encode(model.var_latent_network.packed().handle, C.byref(cfg), C.byref(bufs), stq))
-        _lib.check(L.cs_lair_decode(model.generator_network.packed().handle, C.byref(cfg), C.byref(bufs), C.byref(rng), stq))
-        engine.sample_impute(model, ws.gen, X, M8, K, eps=draws["eps_x"] if draws else None, rng=rng,
-                             stream_id=_lib.STREAM_X)
-        return X, ws.Z[0]

@@ -53,6 +53,12 @@ extern "C" {
 #define CS_RM_MULTINOMIAL 0
 #define CS_RM_SYSTEMATIC 1
 
+/* annealing of the variational proposal towards the prior by the example's fraction of missing
+ * dimensions (VAE.anneal_var_distribution_to_prior_based_on_missingness, vae.py:308-401) */
+#define CS_ANNEAL_NONE 0
+#define CS_ANNEAL_LINEAR 1      /* 'linear'      */
+#define CS_ANNEAL_LINEAR_025 2  /* 'linear_0.25' */
+
 int cs_version(void);
 const char* cs_last_error(void);
 
@@ -128,6 +134,8 @@ typedef struct {
   float weight_alpha;   /* resampling uses alpha*log_w (polynomial transform,
                            test_step_vae_sampling.py:2059-2061); 1 = none */
   int32_t prior;        /* CS_PRIOR_* */
+  float proposal_temperature; /* var_proposal_temperature (0 = off): see cs_proposal_transform */
+  int32_t proposal_anneal;    /* CS_ANNEAL_* (var_proposal_anneal_type_to_prior) */
 } cs_lair_cfg;
 
 typedef struct {
@@ -157,8 +165,20 @@ typedef struct {
   const float* clip_max;
 } cs_lair_bufs;
 
+/* Tempering and annealing of proposal parameters, in place on q[B,K',2,Zd] rows k < K:
+ * VAE.distribution_param_tempering (vae.py:258-306: scale * temperature; Beta: concentrations *
+ * temperature) followed by VAE.anneal_var_distribution_to_prior_based_on_missingness
+ * (vae.py:308-401; mf = fraction of missing dimensions of the example, k_m = (1 - mf) + k*mf with
+ * k = 1/scale (x 0.25 for 'linear_0.25'); scale * k_m, loc * (1 - mf); Beta with the uniform prior:
+ * concentrations * k_m), each including the reference's round trip through
+ * softplus^-1 / softplus (+- 1e-8 for normal_with_eps).  temperature <= 0: no tempering.
+ * M[B,D] is only read when anneal != CS_ANNEAL_NONE. */
+int cs_proposal_transform(float* q, const uint8_t* M, int64_t B, int32_t K, int32_t Kp, int32_t Zd, int32_t D,
+                          int32_t latent_dist, int32_t prior, float temperature, int32_t anneal, void* stream);
+
 /* encoder forward + distribution parameterisation: q[b,k,:] for k < K
- * (vae_imputation.py:551 + vae.py:214-219); rows k >= K of q are set to the prior
+ * (vae_imputation.py:551 + vae.py:214-219), then cs_proposal_transform when the configuration asks
+ * for it (vae_imputation.py:553-561); rows k >= K of q are set to the prior
  * replenishing proposal (loc 0, scale 1; vae_imputation.py:563-577). */
 int cs_lair_encode(const cs_mlp_t* enc, const cs_lair_cfg* cfg, const cs_lair_bufs* b, void* stream);
 /* Z = loc + scale*eps, decoder forward, generator parameterisation, masked log-likelihood
@@ -187,6 +207,8 @@ typedef struct {
   int32_t hist_full; /* 1 once the ring has wrapped */
   int32_t flags;     /* CS_MWG_* bits below; 0 = AC-MWG as published */
   double prior_mixture_probability;
+  float proposal_temperature; /* var_proposal_temperature (0 = off), applied to the step's proposal */
+  int32_t proposal_anneal;    /* CS_ANNEAL_* */
 } cs_acmwg_cfg;
 
 /* Variants of the Metropolis-within-Gibbs step that share the AC-MWG kernels.

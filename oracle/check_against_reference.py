@@ -81,16 +81,17 @@ def make_inputs(B, K, D, seed, miss=0.5):
 # ----------------------------------------------------------------------------------------
 def case_lair(ns, name, *, B, K, R, I, D, Zd, H, nb_enc, nb_dec, seed, scheme="gr",
               weighting="dmis", method="multinomial", cluster=None, resampled_latents=False,
-              iters=2):
+              iters=2, temperature=None, anneal=None, latent_dist="normal_with_eps"):
     enc = O.make_resfc_weights(D, 2 * Zd, nb_enc, H, seed)
     dec = O.make_resfc_weights(Zd, 2 * D, nb_dec, H, seed + 1)
-    vae = ref_vae(ns, enc, dec)
+    vae = ref_vae(ns, enc, dec, latent_dist=latent_dist)
     X, M = make_inputs(B, K, D, seed + 2)
     fx = dict(flat_weights("enc", enc)); fx.update(flat_weights("dec", dec))
     fx.update(X0=X.numpy(), M=M.numpy(),
               cfg=np.array([B, K, R, I, D, Zd, H, cluster or 0, iters], dtype=np.int64),
               scheme=np.array(scheme), weighting=np.array(weighting), method=np.array(method),
-              resampled_latents=np.array(resampled_latents))
+              resampled_latents=np.array(resampled_latents), temperature=np.float64(temperature or 0.0),
+              anneal=np.array(anneal or ""), latent_dist=np.array(latent_dist))
     tape = DrawTape(seed + 3)
     Xr = X.clone()
     for t in range(iters):
@@ -99,7 +100,8 @@ def case_lair(ns, name, *, B, K, R, I, D, Zd, H, nb_enc, nb_dec, seed, scheme="g
             ret = ns.vae_imputation.importance_resampling_gibbs_iteration(
                 vae, Xr, M, I, glr_cluster_size=cluster, weighting=weighting,
                 resampling_method=method, resampling_scheme=scheme,
-                num_prior_replenish_proposals=R, return_resampled_latents=resampled_latents)
+                num_prior_replenish_proposals=R, return_resampled_latents=resampled_latents,
+                var_proposal_temperature=temperature, var_proposal_anneal_type_to_prior=anneal)
         ent = tape.entries[n0:]
         kinds = [k for k, _ in ent]
         res_kind = "multinomial" if method == "multinomial" else "rand"
@@ -112,7 +114,8 @@ def case_lair(ns, name, *, B, K, R, I, D, Zd, H, nb_enc, nb_dec, seed, scheme="g
         o = O.lair_iteration(enc, dec, Xr, M, draws, num_imp_samples=I, weighting=weighting,
                              resampling_scheme=scheme, resampling_method=method,
                              glr_cluster_size=cluster, num_prior_replenish_proposals=R,
-                             return_resampled_latents=resampled_latents)
+                             return_resampled_latents=resampled_latents, latent_dist=latent_dist,
+                             var_proposal_temperature=temperature, var_proposal_anneal_type_to_prior=anneal)
         close(o["X_new"], ret[0], "X_new"); close(o["ess"], ret[1], "ess")
         close(o["transformed_ess"], ret[2], "tess"); close(o["perplexity"], ret[3], "perplexity")
         assert o["total_num_props"] == ret[4]
@@ -145,7 +148,7 @@ BASE_KW = dict(store_last_n_iterations=-1, store_every_n_iterations=1, imputatio
 
 
 def case_acmwg(ns, name, *, B, K, D, Zd, H, seed, warmup, W, T, p, nkpc=None, cluster=None, R=0, plain_mwg=False,
-               ablation=False, clip=False):
+               ablation=False, clip=False, temperature=None, anneal=None):
     """AC-MWG sampler class (or, with plain_mwg, TestVAEMetropolisWithinGibbs) against the oracle."""
     from oracle import cs_oracle_samplers as S
     enc = O.make_resfc_weights(D, 2 * Zd, 1, H, seed)
@@ -153,7 +156,8 @@ def case_acmwg(ns, name, *, B, K, D, Zd, H, seed, warmup, W, T, p, nkpc=None, cl
     vae = ref_vae(ns, enc, dec)
     X, M = make_inputs(B, K, D, seed + 2)
     kw = dict(num_pseudo_warmup_iterations=W, num_mwg_iterations=T,
-              warmup_method=warmup, num_copies=K, clip_imputations_during_pg_warmup=clip, **BASE_KW)
+              warmup_method=warmup, num_copies=K, clip_imputations_during_pg_warmup=clip,
+              var_proposal_temperature=temperature, var_proposal_anneal_type_to_prior=anneal, **BASE_KW)
     if warmup == "irwg":
         kw.update(num_k_per_cluster=nkpc, glr_cluster_size=cluster, num_prior_replenish_proposals=R)
     if plain_mwg:
@@ -173,7 +177,8 @@ def case_acmwg(ns, name, *, B, K, D, Zd, H, seed, warmup, W, T, p, nkpc=None, cl
     okw = dict(num_pseudo_warmup_iterations=W, num_mwg_iterations=T, prior_mixture_probability=p,
                warmup_method=warmup, num_k_per_cluster=nkpc, glr_cluster_size=cluster,
                num_prior_replenish_proposals=R, plain_mwg=plain_mwg, ablation_use_mwg_target=ablation,
-               clip_imputations_during_pg_warmup=clip)
+               clip_imputations_during_pg_warmup=clip, var_proposal_temperature=temperature,
+               var_proposal_anneal_type_to_prior=anneal)
     ora = list(S.acmwg_sampler(enc, dec, X.clone(), M, src, **okw))
     assert src.pos == len(entries), "oracle did not consume the whole tape"
     assert len(ora) == len(ref_out)
@@ -193,7 +198,7 @@ def case_acmwg(ns, name, *, B, K, D, Zd, H, seed, warmup, W, T, p, nkpc=None, cl
     fx.update(X0=X.numpy(), M=M.numpy(),
               cfg=np.array([B, K, D, Zd, H, W, T, nkpc or 0, cluster or 0, R], dtype=np.int64),
               warmup=np.array(warmup), p=np.float64(p), plain_mwg=np.array(plain_mwg), ablation=np.array(ablation),
-              clip=np.array(clip),
+              clip=np.array(clip), temperature=np.float64(temperature or 0.0), anneal=np.array(anneal or ""),
               X_seq=np.stack([r["X"].numpy() for r in ref_out]),
               Z_last=ref_out[-1]["Z"].numpy(),
               acceptance=np.array([float(r["acceptance"]) for r in ref_out], dtype=np.float32),
@@ -326,6 +331,15 @@ def main():
                nkpc=4, cluster=5, R=5)
     case_acmwg(ns, "acmwg_pg_warmup", B=4, K=3, D=7, Zd=3, H=64, seed=808, warmup="pseudo_gibbs", W=3, T=10, p=0.05)
     case_acmwg(ns, "acmwg_nowarmup_noprior", B=4, K=2, D=6, Zd=3, H=64, seed=909, warmup="none", W=0, T=8, p=0.0)
+    case_lair(ns, "lair_tempered_annealed", B=6, K=4, R=1, I=1, D=11, Zd=5, H=64, nb_enc=1, nb_dec=1, seed=414,
+              temperature=1.3, anneal="linear")
+    case_lair(ns, "lair_annealed_025_normal", B=5, K=3, R=0, I=2, D=9, Zd=4, H=64, nb_enc=1, nb_dec=1, seed=424,
+              anneal="linear_0.25", latent_dist="normal")
+    case_lair(ns, "lair_tempered", B=5, K=3, R=2, I=1, D=9, Zd=4, H=64, nb_enc=1, nb_dec=1, seed=434, temperature=0.7)
+    case_acmwg(ns, "acmwg_tempered_annealed", B=4, K=3, D=7, Zd=3, H=64, seed=444, warmup="irwg", W=2, T=10, p=0.1,
+               nkpc=2, cluster=3, R=3, temperature=1.2, anneal="linear_0.25")
+    case_acmwg(ns, "mwg_tempered_annealed", B=4, K=3, D=7, Zd=3, H=64, seed=454, warmup="pseudo_gibbs", W=2, T=10,
+               p=0.0, plain_mwg=True, temperature=0.8, anneal="linear")
     case_acmwg(ns, "acmwg_ablation_mwg_target", B=4, K=3, D=7, Zd=3, H=64, seed=919, warmup="none", W=0, T=10, p=0.1,
                ablation=True)
     case_acmwg(ns, "acmwg_ablation_pg_warmup", B=3, K=2, D=6, Zd=3, H=64, seed=929, warmup="pseudo_gibbs", W=2, T=8,

@@ -188,6 +188,72 @@ def replenish_params(B, R, Zd, dist):
     return torch.cat([means, raw], dim=-1)
 
 
+def _join(a, b):
+    return torch.cat([a, b], dim=-1)
+
+
+def distribution_param_tempering(params, dist, temperature):
+    """VAE.distribution_param_tempering (vae.py:258-306) on raw parameters '... (2 d)'."""
+    d = params.shape[-1] // 2
+    p1, p2 = params[..., :d], params[..., d:]
+    if dist == "normal":
+        scale = F.softplus(p2) * temperature
+        return _join(p1, softplus_inverse(scale))
+    if dist == "normal_with_eps":
+        scale = F.softplus(p2) + EPSILON
+        scale = (scale * temperature) - EPSILON
+        return _join(p1, softplus_inverse(scale))
+    if dist == "beta":
+        return _join(softplus_inverse(F.softplus(p1) * temperature), softplus_inverse(F.softplus(p2) * temperature))
+    raise NotImplementedError(dist)
+
+
+def anneal_var_distribution_to_prior(params, M, dist, anneal_type, prior="std_normal"):
+    """VAE.anneal_var_distribution_to_prior_based_on_missingness (vae.py:308-401).  M bool
+    [B,1,D] broadcasts against params [B,K,2d]."""
+    if anneal_type == "linear":
+        const = None
+    elif anneal_type == "linear_0.25":
+        const = 0.25
+    else:
+        raise NotImplementedError(anneal_type)
+
+    def anneal(k):
+        mf = (M.shape[-1] - M.sum(dim=-1, keepdim=True)) / M.shape[-1]
+        if const is None:
+            return 1 * (1 - mf) + k * mf
+        return 1 * (1 - mf) + k * const * mf
+
+    d = params.shape[-1] // 2
+    p1, p2 = params[..., :d], params[..., d:]
+    if dist in ("normal", "normal_with_eps") and prior == "std_normal":
+        eps = EPSILON if dist == "normal_with_eps" else None
+        scale = F.softplus(p2)
+        if eps is not None:
+            scale = scale + eps
+        k_m = anneal(1.0 / scale)
+        scale = scale * k_m
+        if eps is not None:
+            scale = scale - eps
+        raw = softplus_inverse(scale)
+        loc = p1 * anneal(0)
+        return _join(loc, raw)
+    if dist == "beta" and prior == "uniform":
+        alpha, beta = F.softplus(p1), F.softplus(p2)
+        return _join(softplus_inverse(alpha * anneal(1.0 / alpha)), softplus_inverse(beta * anneal(1.0 / beta)))
+    raise NotImplementedError((dist, prior))
+
+
+def transform_proposal_params(params, M, dist, temperature=None, anneal_type=None, prior="std_normal"):
+    """Tempering then annealing, as every call site of the reference orders them
+    (vae_imputation.py:553-561, test_step_vae_sampling.py:1222-1230, 1672-1680)."""
+    if temperature is not None:
+        params = distribution_param_tempering(params, dist, temperature)
+    if anneal_type is not None:
+        params = anneal_var_distribution_to_prior(params, M, dist, anneal_type, prior)
+    return params
+
+
 # --------------------------------------------------------------------------------------
 # categorical sampling with injected uniforms
 # --------------------------------------------------------------------------------------
@@ -336,7 +402,8 @@ def lair_iteration(enc, dec, X, M, draws, *, num_imp_samples=1, weighting="dmis"
                    glr_cluster_size=None, num_prior_replenish_proposals=0,
                    latent_dist="normal_with_eps", gen_dist="normal_with_eps",
                    return_resampled_latents=False, weight_alpha=None,
-                   encoder=None, decoder=None, prior="std_normal"):
+                   encoder=None, decoder=None, prior="std_normal",
+                   var_proposal_temperature=None, var_proposal_anneal_type_to_prior=None):
     """One LAIR step (vae_imputation.py:484-726) with injected draws.  For latent_dist='beta'
     'eps_z' holds the Beta samples themselves (torch draws them by rejection sampling).
 
@@ -354,6 +421,8 @@ def lair_iteration(enc, dec, X, M, draws, *, num_imp_samples=1, weighting="dmis"
     out = {}
 
     var_params = encoder(X)                                   # [B,K,2Zd]
+    var_params = transform_proposal_params(var_params, M, latent_dist, var_proposal_temperature,
+                                           var_proposal_anneal_type_to_prior, prior)   # :553-561
     Zd = var_params.shape[-1] // 2
     Xp = X
     if R > 0:
@@ -536,7 +605,8 @@ class RestrictedHistory:
 
 def acmwg_step(enc, dec, state, M, hist_X, draws, *, prior_mixture_probability,
                latent_dist="normal_with_eps", gen_dist="normal_with_eps",
-               encoder=None, decoder=None, joint_target_new=False, joint_target_old=False):
+               encoder=None, decoder=None, joint_target_new=False, joint_target_old=False,
+               var_proposal_temperature=None, var_proposal_anneal_type_to_prior=None):
     """One AC-MWG step (test_step_vae_sampling.py:1671-1755).  The plain Metropolis-within-Gibbs
     step (:1221-1269) is the same arithmetic with ``hist_X`` = the current imputations, no prior
     mixture, and both log-likelihoods summed over all dimensions (``joint_target_new/old``);
@@ -550,7 +620,9 @@ def acmwg_step(enc, dec, state, M, hist_X, draws, *, prior_mixture_probability,
     decoder = decoder or (lambda z: resfc_forward(dec, z))
     X, Z_old = state["X"], state["Z_old"]
     p = prior_mixture_probability
-    q_loc, q_scale = split_loc_scale(encoder(hist_X), latent_dist)
+    var_params = transform_proposal_params(encoder(hist_X), M, latent_dist, var_proposal_temperature,
+                                           var_proposal_anneal_type_to_prior)   # :1672-1680
+    q_loc, q_scale = split_loc_scale(var_params, latent_dist)
     Z_new = q_loc + q_scale * draws["eps_z"]
     out = {}
     if p > 0.0:

@@ -142,7 +142,8 @@ def lair_sampler(enc, dec, X, M, src, *, num_iterations, num_imp_samples=1, weig
                  resampling_scheme="gr", resampling_method="multinomial", glr_cluster_size=None,
                  num_prior_replenish_proposals=0, prior_replenish_iteration_frequency=1, store_latents=False,
                  clip_imputations=False, weight_transform=None, latent_dist="normal_with_eps",
-                 gen_dist="normal_with_eps", collect_proposals=False, prior="std_normal"):
+                 gen_dist="normal_with_eps", collect_proposals=False, prior="std_normal",
+                 var_proposal_temperature=None, var_proposal_anneal_type_to_prior=None):
     """Generator over LAIR iterations; yields the dict the reference yields plus, when
     ``collect_proposals``, 'Z_prop' and 'log_weights' for the final resampling."""
     B, K, D = X.shape
@@ -163,7 +164,8 @@ def lair_sampler(enc, dec, X, M, src, *, num_iterations, num_imp_samples=1, weig
                              resampling_scheme=resampling_scheme, resampling_method=resampling_method,
                              glr_cluster_size=glr_cluster_size, num_prior_replenish_proposals=R,
                              latent_dist=latent_dist, gen_dist=gen_dist, return_resampled_latents=store_latents,
-                             weight_alpha=alpha)
+                             weight_alpha=alpha, var_proposal_temperature=var_proposal_temperature,
+                             var_proposal_anneal_type_to_prior=var_proposal_anneal_type_to_prior)
         X_m = o["X_new"]
         if clip_imputations:
             X_m = torch.min(torch.max(X_m, clip_min), clip_max)
@@ -211,7 +213,8 @@ def acmwg_sampler(enc, dec, X, M, src, *, num_pseudo_warmup_iterations, num_mwg_
                   weighting_scheme="dmis_within_groups", resampling_scheme="glr",
                   resampling_method="multinomial", enqueue_allwarmup_samples_to_history=False,
                   latent_dist="normal_with_eps", gen_dist="normal_with_eps", ablation_use_mwg_target=False,
-                  plain_mwg=False, clip_imputations_during_pg_warmup=False):
+                  plain_mwg=False, clip_imputations_during_pg_warmup=False,
+                  var_proposal_temperature=None, var_proposal_anneal_type_to_prior=None):
     """Generator over AC-MWG iterations (warm-up iterations included), yielding
     {'X','Z' (absent during the irwg warm-up),'acceptance'} like the reference; MWG steps also
     carry 'accepted', 'log_accept' and 'slots' for the parity tests.
@@ -223,6 +226,8 @@ def acmwg_sampler(enc, dec, X, M, src, *, num_pseudo_warmup_iterations, num_mwg_
     B, K, D = X.shape
     Zd = O.net_input_dim(dec)
     W = num_pseudo_warmup_iterations
+    tkw = dict(var_proposal_temperature=var_proposal_temperature,
+               var_proposal_anneal_type_to_prior=var_proposal_anneal_type_to_prior)
     if warmup_method == "irwg":
         max_it = W * num_k_per_cluster + num_mwg_iterations
     else:
@@ -271,7 +276,7 @@ def acmwg_sampler(enc, dec, X, M, src, *, num_pseudo_warmup_iterations, num_mwg_
                                   weighting=weighting_scheme, resampling_scheme=resampling_scheme,
                                   resampling_method=resampling_method, glr_cluster_size=c,
                                   num_prior_replenish_proposals=R, latent_dist=latent_dist,
-                                  gen_dist=gen_dist)["X_new"]
+                                  gen_dist=gen_dist, **tkw)["X_new"]
             # 'b (c k) -> b k c' with c = glr_cluster_size (:1611): k' = cc*(Kw/c) + kk
             Xt = Xw.reshape(B, c, Kw // c, D).permute(0, 2, 1, 3).contiguous()   # b k c d
             if R > 0:
@@ -300,7 +305,8 @@ def acmwg_sampler(enc, dec, X, M, src, *, num_pseudo_warmup_iterations, num_mwg_
             draws = {"eps_z": src.normal(B, K, Zd), "u_accept": src.uniform(B, K),
                      "eps_x": src.uniform(B, K, D) if gen_dist == "bern" else src.normal(B, K, D)}
             o = O.acmwg_step(enc, dec, state, M, state["X"], draws, prior_mixture_probability=0.0,
-                             latent_dist=latent_dist, gen_dist=gen_dist, joint_target_new=True, joint_target_old=True)
+                             latent_dist=latent_dist, gen_dist=gen_dist, joint_target_new=True, joint_target_old=True,
+                             **tkw)
             state = o["state"]
             yield {"X": state["X"], "Z": state["Z_old"], "acceptance": o["acceptance"], "accepted": o["accepted"],
                    "log_accept": o["log_accept"]}
@@ -321,7 +327,7 @@ def acmwg_sampler(enc, dec, X, M, src, *, num_pseudo_warmup_iterations, num_mwg_
         draws["u_accept"] = src.uniform(B, K)
         draws["eps_x"] = src.uniform(B, K, D) if gen_dist == "bern" else src.normal(B, K, D)
         o = O.acmwg_step(enc, dec, state, M, hist_X, draws, prior_mixture_probability=prior_mixture_probability,
-                         latent_dist=latent_dist, gen_dist=gen_dist, joint_target_new=ablation_use_mwg_target)
+                         latent_dist=latent_dist, gen_dist=gen_dist, joint_target_new=ablation_use_mwg_target, **tkw)
         hist.update_available(o["accepted"])
         state = o["state"]
         hist.enqueue(state["X"])

@@ -18,7 +18,8 @@ from tests.helpers import (RTOL, assert_close, load_golden, make_model, seeded_i
 pytestmark = pytest.mark.gpu
 
 LAIR_CASES = ["lair_gr_mult_small", "lair_gr_mult_i2_lat", "lair_gr_mult_noreplenish", "lair_gr_syst",
-              "lair_glr_groups", "lair_miniboone_shape"]
+              "lair_glr_groups", "lair_miniboone_shape", "lair_tempered_annealed", "lair_annealed_025_normal",
+              "lair_tempered"]
 
 
 @pytest.fixture(scope="module")
@@ -48,9 +49,11 @@ def test_lair_iteration_matches_reference_golden(name):
     from vae_conditional_sampling_amd.sampling.vae_imputation import importance_resampling_gibbs_iteration
     fx = load_golden(name)
     B, K, R, I, D, Zd, H, cluster, iters = [int(v) for v in fx["cfg"]]
-    model = make_model(weights_from_fixture(fx, "enc"), weights_from_fixture(fx, "dec"))
+    latent_dist = str(fx["latent_dist"])
+    model = make_model(weights_from_fixture(fx, "enc"), weights_from_fixture(fx, "dec"), latent_dist=latent_dist)
     scheme, weighting, method = str(fx["scheme"]), str(fx["weighting"]), str(fx["method"])
     want_lat = bool(fx["resampled_latents"])
+    temperature, anneal = float(fx["temperature"]) or None, str(fx["anneal"]) or None
     X = torch.from_numpy(fx["X0"]).cuda()
     M = torch.from_numpy(fx["M"]).cuda()
     for t in range(iters):
@@ -61,7 +64,7 @@ def test_lair_iteration_matches_reference_golden(name):
         out = importance_resampling_gibbs_iteration(
             model, X, M, I, glr_cluster_size=cluster or None, weighting=weighting, resampling_method=method,
             resampling_scheme=scheme, num_prior_replenish_proposals=R, return_resampled_latents=want_lat,
-            draws=draws)
+            var_proposal_temperature=temperature, var_proposal_anneal_type_to_prior=anneal, draws=draws)
         ws = model._cs_workspaces[("lair", B, K, R, I, str(X.device))]
         assert_close(ws.q[:, :, 0], fx[f"t{t}_q_loc"], "q loc")
         assert_close(ws.q[:, :, 1], fx[f"t{t}_q_scale"], "q scale")

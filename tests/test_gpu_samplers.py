@@ -26,7 +26,8 @@ def tape_source(fx):
 
 @pytest.mark.parametrize("name", ["acmwg_irwg_warmup", "acmwg_pg_warmup", "acmwg_nowarmup_noprior",
                                   "acmwg_ablation_mwg_target", "acmwg_ablation_pg_warmup",
-                                  "mwg_pg_warmup_clip", "mwg_nowarmup", "mwg_irwg_warmup"])
+                                  "mwg_pg_warmup_clip", "mwg_nowarmup", "mwg_irwg_warmup",
+                                  "acmwg_tempered_annealed", "mwg_tempered_annealed"])
 def test_acmwg_sampler_matches_reference_golden(name):
     """AC-MWG (incl. its ablation_use_mwg_target) and the plain Metropolis-within-Gibbs class."""
     from vae_conditional_sampling_amd.sampling import test_step_vae_sampling as TS
@@ -35,7 +36,9 @@ def test_acmwg_sampler_matches_reference_golden(name):
     warmup = str(fx["warmup"])
     model = make_model(weights_from_fixture(fx, "enc"), weights_from_fixture(fx, "dec"))
     kw = dict(num_pseudo_warmup_iterations=W, num_mwg_iterations=T, warmup_method=warmup, num_copies=K,
-              clip_imputations_during_pg_warmup=bool(fx["clip"]), **BASE_KW)
+              clip_imputations_during_pg_warmup=bool(fx["clip"]),
+              var_proposal_temperature=float(fx["temperature"]) or None,
+              var_proposal_anneal_type_to_prior=str(fx["anneal"]) or None, **BASE_KW)
     if warmup == "irwg":
         kw.update(num_k_per_cluster=nkpc, glr_cluster_size=cluster, num_prior_replenish_proposals=R)
     if bool(fx["plain_mwg"]):

@@ -50,7 +50,7 @@ def test_unsupported_options_raise_not_implemented():
     X = torch.zeros(2, 2, 3); M = torch.ones(2, 1, 3, dtype=torch.bool)
     for bad in (dict(resampling_scheme="lr"), dict(resampling_scheme="ir"), dict(weighting="nope"),
                 dict(resampling_method="residual"), dict(use_historical_proposals=True),
-                dict(var_proposal_temperature=0.5), dict(accept_reject_xm=True)):
+                dict(var_proposal_anneal_type_to_prior="quadratic"), dict(accept_reject_xm=True)):
         with pytest.raises(NotImplementedError):
             importance_resampling_gibbs_iteration(None, X, M, 1, **bad)
 

@@ -14,7 +14,8 @@ from oracle import cs_oracle_samplers as S
 from tests.helpers import assert_close, load_golden, weights_from_fixture
 
 LAIR_CASES = ["lair_gr_mult_small", "lair_gr_mult_i2_lat", "lair_gr_mult_noreplenish", "lair_gr_syst",
-              "lair_glr_groups", "lair_miniboone_shape"]
+              "lair_glr_groups", "lair_miniboone_shape", "lair_tempered_annealed", "lair_annealed_025_normal",
+              "lair_tempered"]
 
 
 @pytest.mark.parametrize("name", LAIR_CASES)
@@ -31,7 +32,9 @@ def test_oracle_lair_iteration(name):
         o = O.lair_iteration(enc, dec, X, M, draws, num_imp_samples=I, weighting=str(fx["weighting"]),
                              resampling_scheme=str(fx["scheme"]), resampling_method=str(fx["method"]),
                              glr_cluster_size=cluster or None, num_prior_replenish_proposals=R,
-                             return_resampled_latents=want_lat)
+                             return_resampled_latents=want_lat, latent_dist=str(fx["latent_dist"]),
+                             var_proposal_temperature=float(fx["temperature"]) or None,
+                             var_proposal_anneal_type_to_prior=str(fx["anneal"]) or None)
         assert_close(o["log_weights"], fx[f"t{t}_log_weights"], "log_weights")
         assert np.array_equal(o["idx_global"].numpy(), fx[f"t{t}_idx"])
         assert_close(o["X_new"], fx[f"t{t}_X_new"], "X_new")
@@ -42,7 +45,7 @@ def test_oracle_lair_iteration(name):
         X = o["X_new"]
 
 
-MWG_CASES = ["acmwg_irwg_warmup", "acmwg_pg_warmup", "acmwg_nowarmup_noprior", "acmwg_ablation_mwg_target",
+MWG_CASES = ["acmwg_tempered_annealed", "mwg_tempered_annealed", "acmwg_irwg_warmup", "acmwg_pg_warmup", "acmwg_nowarmup_noprior", "acmwg_ablation_mwg_target",
              "acmwg_ablation_pg_warmup", "mwg_pg_warmup_clip", "mwg_nowarmup", "mwg_irwg_warmup"]
 
 
@@ -58,7 +61,9 @@ def test_oracle_acmwg_sampler(name):
                                 num_k_per_cluster=nkpc or None, glr_cluster_size=cluster or None,
                                 num_prior_replenish_proposals=R, plain_mwg=bool(fx["plain_mwg"]),
                                 ablation_use_mwg_target=bool(fx["ablation"]),
-                                clip_imputations_during_pg_warmup=bool(fx["clip"])))
+                                clip_imputations_during_pg_warmup=bool(fx["clip"]),
+                                var_proposal_temperature=float(fx["temperature"]) or None,
+                                var_proposal_anneal_type_to_prior=str(fx["anneal"]) or None))
     assert src.pos == len(src.entries)
     mwg = [o for o in outs if "accepted" in o]
     assert np.array_equal(np.stack([o["accepted"].numpy() for o in mwg]), fx["accepted"])

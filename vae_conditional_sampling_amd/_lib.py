@@ -17,6 +17,17 @@ CS_PRIOR = {"std_normal": 0, "uniform": 1}
 CS_WEIGHTING = {"dmis": 0, "dmis_within_groups": 1, "smis": 2}
 CS_SCHEME = {"gr": 0, "glr": 1}
 CS_METHOD = {"multinomial": 0, "systematic": 1}
+CS_ANNEAL = {None: 0, "linear": 1, "linear_0.25": 2}
+
+
+def proposal_transform_args(temperature, anneal_type):
+    """(temperature, CS_ANNEAL_*) of var_proposal_temperature / var_proposal_anneal_type_to_prior."""
+    if anneal_type not in CS_ANNEAL:
+        raise NotImplementedError(f'Method not implemented for anneal_type = {anneal_type!r}')
+    if temperature is not None and not temperature > 0:
+        raise ValueError("var_proposal_temperature must be positive")
+    return float(temperature or 0.0), CS_ANNEAL[anneal_type]
+
 
 # stream ids of the counter RNG (csrc/cs_common.h, enum CsStream)
 STREAM_Z, STREAM_X, STREAM_URES, STREAM_URES2 = 1, 2, 3, 4
@@ -55,7 +66,7 @@ class cs_lair_cfg(C.Structure):
                 ("D", C.c_int32), ("Zd", C.c_int32), ("latent_dist", C.c_int32),
                 ("gen_dist", C.c_int32), ("weighting", C.c_int32), ("scheme", C.c_int32),
                 ("method", C.c_int32), ("cluster_size", C.c_int32), ("weight_alpha", C.c_float),
-                ("prior", C.c_int32)]
+                ("prior", C.c_int32), ("proposal_temperature", C.c_float), ("proposal_anneal", C.c_int32)]
 
 
 _LAIR_BUF_FIELDS = ["X", "M", "eps_z", "u_res", "u_res2", "u_sys", "u_sys2", "eps_x", "q", "Z", "gen",
@@ -71,7 +82,8 @@ class cs_acmwg_cfg(C.Structure):
     _fields_ = [("B", C.c_int32), ("K", C.c_int32), ("D", C.c_int32), ("Zd", C.c_int32),
                 ("latent_dist", C.c_int32), ("gen_dist", C.c_int32), ("hist_len", C.c_int32),
                 ("hist_tail", C.c_int32), ("hist_full", C.c_int32), ("flags", C.c_int32),
-                ("prior_mixture_probability", C.c_double)]
+                ("prior_mixture_probability", C.c_double), ("proposal_temperature", C.c_float),
+                ("proposal_anneal", C.c_int32)]
 
 
 _ACMWG_BUF_FIELDS = ["X", "M", "Z_old", "gen_old", "z_old_prior_lp", "x_old_lp", "ring", "avail", "r_hist",
@@ -111,6 +123,7 @@ def lib():
     L.cs_mlp_destroy.argtypes = [vp]
     L.cs_net_create.argtypes = [C.POINTER(cs_layer_desc), i32, vp, i64, i32, i32, i32, C.POINTER(vp)]
     L.cs_mlp_forward.argtypes = [vp, vp, i64, vp, vp]
+    L.cs_proposal_transform.argtypes = [vp, vp, i64, i32, i32, i32, i32, i32, i32, C.c_float, i32, vp]
     L.cs_lair_encode.argtypes = [vp, C.POINTER(cs_lair_cfg), C.POINTER(cs_lair_bufs), vp]
     L.cs_lair_decode.argtypes = [vp, C.POINTER(cs_lair_cfg), C.POINTER(cs_lair_bufs), C.POINTER(cs_rng), vp]
     L.cs_lair_resample_impute.argtypes = [C.POINTER(cs_lair_cfg), C.POINTER(cs_lair_bufs), C.POINTER(cs_rng), vp]

@@ -301,6 +301,10 @@ extern "C" int cs_acmwg_step(const cs_mlp_t* enc, const cs_mlp_t* dec, const cs_
   fill_mlp_common(e, c);
   e.latent_dist = c->latent_dist;
   if (int rc = cs_mlp_launch(e, st)) return rc;
+  if (c->proposal_temperature > 0.0f || c->proposal_anneal != CS_ANNEAL_NONE)  // :1672-1680, :1222-1230
+    if (int rc = cs_proposal_transform(b->q, b->M, c->B, c->K, c->K, c->Zd, c->D, c->latent_dist, CS_PRIOR_STD_NORMAL,
+                                       c->proposal_temperature, c->proposal_anneal, stream))
+      return rc;
   CsMlpArgs d;
   std::memset(&d, 0, sizeof(d));
   d.net = dec->dev; d.mode = CS_MLP_DEC; d.rows = chains;

@@ -337,6 +337,77 @@ static int check_cfg(const cs_lair_cfg* c, const cs_lair_bufs* b) {
   return CS_OK;
 }
 
+// ----------------------------------------------------------------------------------------
+// Proposal tempering / annealing to the prior (vae.py:258-401), in place on q.  One wavefront per
+// example: the missing fraction is a wave reduction over the mask row, then the K*Zd parameter
+// pairs of the example are transformed with the reference's float32 operation order, including
+// its round trip raw = softplus^-1(scale'), scale'' = softplus(raw) (+- 1e-8).
+// ----------------------------------------------------------------------------------------
+struct CsPropTransformArgs {
+  float* q; const uint8_t* M; int64_t B; int K, Kp, Zd, D, latent_dist; float temperature; int anneal;
+};
+
+__device__ __forceinline__ float cs_softplus_inverse_ref(float x) { return x + logf(-expm1f(-x)); }  // softplus_inverse.py:3-7
+__device__ __forceinline__ float cs_softplus_ref(float x) { return x > 20.0f ? x : log1pf(expf(x)); }
+
+__global__ void __launch_bounds__(256) cs_proposal_transform_kernel(const CsPropTransformArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int64_t b = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (b >= a.B) return;
+  float mf = 0.0f;
+  if (a.anneal != CS_ANNEAL_NONE) {
+    int obs = 0;
+    for (int d = lane; d < a.D; d += 64) obs += a.M[b * a.D + d] ? 1 : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) obs += __shfl_xor(obs, o);
+    mf = (float)(a.D - obs) / (float)a.D;
+  }
+  const float eps = a.latent_dist == CS_DIST_NORMAL_WITH_EPS ? 1e-8f : 0.0f;
+  const float kc = a.anneal == CS_ANNEAL_LINEAR_025 ? 0.25f : 1.0f;
+  const bool beta = a.latent_dist == CS_DIST_BETA;
+  // one positive parameter through tempering and annealing
+  auto pos = [&](float s) {
+    if (a.temperature > 0.0f) s = cs_softplus_ref(cs_softplus_inverse_ref(s * a.temperature - eps)) + eps;
+    if (a.anneal != CS_ANNEAL_NONE) {
+      const float k = 1.0f / s;
+      const float km = (1.0f - mf) + (a.anneal == CS_ANNEAL_LINEAR_025 ? (k * kc) * mf : k * mf);
+      s = cs_softplus_ref(cs_softplus_inverse_ref(s * km - eps)) + eps;
+    }
+    return s;
+  };
+  for (int t = lane; t < a.K * a.Zd; t += 64) {
+    const int k = t / a.Zd, z = t - k * a.Zd;
+    float* qr = a.q + (b * a.Kp + k) * 2 * a.Zd;
+    if (beta) {
+      qr[z] = pos(qr[z]);
+    } else if (a.anneal != CS_ANNEAL_NONE) {
+      qr[z] = qr[z] * ((1.0f - mf) + 0.0f * mf);
+    }
+    qr[a.Zd + z] = pos(qr[a.Zd + z]);
+  }
+}
+
+extern "C" int cs_proposal_transform(float* q, const uint8_t* M, int64_t B, int32_t K, int32_t Kp, int32_t Zd, int32_t D,
+                                     int32_t latent_dist, int32_t prior, float temperature, int32_t anneal, void* stream) {
+  CS_REQUIRE(q && B >= 0 && K >= 1 && Kp >= K && Zd >= 1 && D >= 1, "bad argument");
+  CS_REQUIRE(anneal >= CS_ANNEAL_NONE && anneal <= CS_ANNEAL_LINEAR_025, "bad anneal type");
+  CS_REQUIRE(latent_dist == CS_DIST_NORMAL || latent_dist == CS_DIST_NORMAL_WITH_EPS || latent_dist == CS_DIST_BETA,
+             "latent distribution must be normal / normal_with_eps / beta");
+  if (anneal != CS_ANNEAL_NONE) {
+    CS_REQUIRE(M, "annealing needs the mask");
+    // the reference defines the annealing for (normal posterior, normal prior) and (Beta, uniform) only
+    if ((latent_dist == CS_DIST_BETA) != (prior == CS_PRIOR_UNIFORM))
+      return cs_fail(CS_EUNSUPPORTED, "annealing is not defined for this posterior / prior pair");
+  }
+  if (B == 0 || (!(temperature > 0.0f) && anneal == CS_ANNEAL_NONE)) return CS_OK;
+  CsPropTransformArgs a;
+  a.q = q; a.M = M; a.B = B; a.K = K; a.Kp = Kp; a.Zd = Zd; a.D = D; a.latent_dist = latent_dist;
+  a.temperature = temperature; a.anneal = anneal;
+  hipLaunchKernelGGL(cs_proposal_transform_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);
+  CS_HIP(hipGetLastError());
+  return CS_OK;
+}
+
 extern "C" int cs_lair_encode(const cs_mlp_t* enc, const cs_lair_cfg* c, const cs_lair_bufs* b, void* stream) {
   if (int rc = check_cfg(c, b)) return rc;
   if (c->B == 0) return CS_OK;  // empty batch: nothing to do (its tensors have no storage)
@@ -353,7 +424,11 @@ extern "C" int cs_lair_encode(const cs_mlp_t* enc, const cs_lair_cfg* c, const c
   a.q = b->q;
   a.K = c->K; a.Kp = c->K + c->R; a.Zd = c->Zd; a.B = c->B; a.I = c->I; a.D = c->D;
   a.latent_dist = c->latent_dist;
-  return cs_mlp_launch(a, (hipStream_t)stream);
+  if (int rc = cs_mlp_launch(a, (hipStream_t)stream)) return rc;
+  if (c->proposal_temperature > 0.0f || c->proposal_anneal != CS_ANNEAL_NONE)
+    return cs_proposal_transform(b->q, b->M, c->B, c->K, c->K + c->R, c->Zd, c->D, c->latent_dist, c->prior,
+                                 c->proposal_temperature, c->proposal_anneal, stream);
+  return CS_OK;
 }
 
 extern "C" int cs_lair_decode(const cs_mlp_t* dec, const cs_lair_cfg* c, const cs_lair_bufs* b, const cs_rng* rng,

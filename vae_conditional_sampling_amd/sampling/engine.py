@@ -56,7 +56,7 @@ def lair_workspace(model, B, K, R, I, device):
     return ws
 
 
-def lair_cfg(model, ws, *, weighting, scheme, method, cluster_size, weight_alpha):
+def lair_cfg(model, ws, *, weighting, scheme, method, cluster_size, weight_alpha, temperature=None, anneal_type=None):
     latent, gen = model.engine_dists()
     try:
         w = _lib.CS_WEIGHTING[weighting]
@@ -64,9 +64,10 @@ def lair_cfg(model, ws, *, weighting, scheme, method, cluster_size, weight_alpha
         m = _lib.CS_METHOD[method]
     except KeyError:
         raise NotImplementedError(f"{weighting=}, {scheme=}, {method=}")
+    temp, anneal = _lib.proposal_transform_args(temperature, anneal_type)
     return _lib.cs_lair_cfg(ws.B, ws.K, ws.R, ws.I, ws.D, ws.Zd, latent, gen, w, s, m,
                             int(cluster_size or 0), float(1.0 if weight_alpha is None else weight_alpha),
-                            model.engine_prior())
+                            model.engine_prior(), temp, anneal)
 
 
 def lair_step(model, ws, X, M8, cfg, *, rng=None, draws=None, return_resampled_latents=False,

@@ -361,8 +361,7 @@ class TestVAELatentAdaptiveImportanceResampling(TestVAESamplerBase):
             raise NotImplementedError("historical proposals are not implemented")
         if hp.use_miss_model or hp.accept_reject_xm:
             raise NotImplementedError("missingness models (MNAR) are not implemented")
-        if hp.var_proposal_temperature is not None or hp.var_proposal_anneal_type_to_prior is not None:
-            raise NotImplementedError("proposal tempering / annealing is not implemented")
+        _lib.proposal_transform_args(hp.var_proposal_temperature, hp.var_proposal_anneal_type_to_prior)
         if hp.weight_transform not in (None, 'poly'):
             raise NotImplementedError()
 
@@ -436,6 +435,8 @@ class TestVAELatentAdaptiveImportanceResampling(TestVAESamplerBase):
                 weighting=hp.weighting_scheme, resampling_method=hp.resampling_method,
                 resampling_scheme=hp.resampling_scheme, num_prior_replenish_proposals=R,
                 weight_transform=weight_transform, return_resampled_latents=bool(hp.store_latents),
+                var_proposal_temperature=hp.var_proposal_temperature,
+                var_proposal_anneal_type_to_prior=hp.var_proposal_anneal_type_to_prior,
                 rng=self._rng(), draws=self._draws(B, K, R, D, bool(hp.store_latents)),
                 clip_min=clip_min, clip_max=clip_max, inplace=True)
             self._next_iteration()
@@ -592,8 +593,7 @@ class _MetropolisWithinGibbsCommon(TestVAESamplerBase):
     def on_test_start(self):
         super().on_test_start()
         hp = self.hparams
-        if hp.var_proposal_temperature is not None or hp.var_proposal_anneal_type_to_prior is not None:
-            raise NotImplementedError("proposal tempering / annealing is not implemented")
+        _lib.proposal_transform_args(hp.var_proposal_temperature, hp.var_proposal_anneal_type_to_prior)
         if hp.warmup_method not in ('none', 'pseudo_gibbs', 'irwg'):
             raise NotImplementedError(f'{hp.warmup_method=}')
 
@@ -650,8 +650,9 @@ class _MetropolisWithinGibbsCommon(TestVAESamplerBase):
             ret = importance_resampling_gibbs_iteration(
                 model, X_w, M, hp.num_imp_samples, glr_cluster_size=c, weighting=hp.weighting_scheme,
                 resampling_method=hp.resampling_method, resampling_scheme=hp.resampling_scheme,
-                num_prior_replenish_proposals=R, rng=self._rng(), draws=self._lair_warmup_draws(B, Kw, R, D),
-                inplace=True)
+                num_prior_replenish_proposals=R, var_proposal_temperature=hp.var_proposal_temperature,
+                var_proposal_anneal_type_to_prior=hp.var_proposal_anneal_type_to_prior,
+                rng=self._rng(), draws=self._lair_warmup_draws(B, Kw, R, D), inplace=True)
             self._next_iteration()
             X_w = ret[0]
             # 'b (c k) -> b k c' (:1611), padded to K chains by repeating the first ones (:1613-1615)
@@ -771,7 +772,8 @@ class TestVAEMetropolisWithinGibbs(_MetropolisWithinGibbsCommon):
         h_dec = model.generator_network.packed().handle
         stream = _lib.current_stream()
         flags = _lib.CS_MWG_PROPOSE_FROM_CURRENT | _lib.CS_MWG_JOINT_TARGET_NEW | _lib.CS_MWG_JOINT_TARGET_OLD
-        cfg = _lib.cs_acmwg_cfg(B, K, D, Zd, latent, gen_dist, 1, 0, 0, flags, 0.0)
+        temp, anneal = _lib.proposal_transform_args(hp.var_proposal_temperature, hp.var_proposal_anneal_type_to_prior)
+        cfg = _lib.cs_acmwg_cfg(B, K, D, Zd, latent, gen_dist, 1, 0, 0, flags, 0.0, temp, anneal)
 
         if hp.warmup_method == 'pseudo_gibbs':
             self._state_after_pseudo_gibbs(st, X, M8, joint=True)
@@ -879,10 +881,12 @@ class TestVAEAdaptiveCollapsedMetropolisWithinGibbs(_MetropolisWithinGibbsCommon
         ablation = bool(hp.ablation_use_mwg_target)
         flags = _lib.CS_MWG_JOINT_TARGET_NEW if ablation else 0
 
+        temp, anneal = _lib.proposal_transform_args(hp.var_proposal_temperature, hp.var_proposal_anneal_type_to_prior)
+
         def cfg_now(flags=flags):
             return _lib.cs_acmwg_cfg(B, K, D, Zd, latent, gen_dist, history.max_history_length,
                                      max(history.tail_idx, 0), int(history.full), flags,
-                                     float(hp.prior_mixture_probability))
+                                     float(hp.prior_mixture_probability), temp, anneal)
 
         if hp.warmup_method == 'pseudo_gibbs':
             self._state_after_pseudo_gibbs(st, X, M8, joint=ablation)

@@ -19,14 +19,11 @@ def expand_M_dim(M, *, data_channel_dim=None):
     return M
 
 
-def _check_common(miss_model, accept_reject_xm, data_channel_dim, var_proposal_temperature,
-                  var_proposal_anneal_type_to_prior):
+def _check_common(miss_model, accept_reject_xm, data_channel_dim):
     if miss_model is not None or accept_reject_xm:
         raise NotImplementedError("missingness models (MNAR) are not implemented")
     if data_channel_dim is not None:
         raise NotImplementedError("data_channel_dim is not implemented")
-    if var_proposal_temperature is not None or var_proposal_anneal_type_to_prior is not None:
-        raise NotImplementedError("proposal tempering / annealing is not implemented")
 
 
 def importance_resampling_gibbs_iteration(model, X, M, num_imp_samples, *, glr_cluster_size=None,
@@ -51,8 +48,8 @@ def importance_resampling_gibbs_iteration(model, X, M, num_imp_samples, *, glr_c
     ``weight_transform`` may be ``None`` or a float alpha (log-weights are multiplied by it
     before resampling: the 'poly' transform of the sampler class).  The tensors returned are
     views of the model's workspace and are overwritten by the next call (clone to keep)."""
-    _check_common(miss_model, accept_reject_xm, data_channel_dim, var_proposal_temperature,
-                  var_proposal_anneal_type_to_prior)
+    _check_common(miss_model, accept_reject_xm, data_channel_dim)
+    _lib.proposal_transform_args(var_proposal_temperature, var_proposal_anneal_type_to_prior)
     if use_historical_proposals:
         raise NotImplementedError("historical proposals are not implemented")
     if weighting not in ("dmis", "dmis_within_groups", "smis"):
@@ -69,7 +66,8 @@ def importance_resampling_gibbs_iteration(model, X, M, num_imp_samples, *, glr_c
     R = int(num_prior_replenish_proposals)
     ws = engine.lair_workspace(model, B, K, R, int(num_imp_samples), X.device)
     cfg = engine.lair_cfg(model, ws, weighting=weighting, scheme=resampling_scheme, method=resampling_method,
-                          cluster_size=glr_cluster_size, weight_alpha=weight_transform)
+                          cluster_size=glr_cluster_size, weight_alpha=weight_transform,
+                          temperature=var_proposal_temperature, anneal_type=var_proposal_anneal_type_to_prior)
     X_new = X if inplace else X.clone()
     if not X_new.is_contiguous():
         X_new = X_new.contiguous()

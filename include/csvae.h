@@ -50,6 +50,8 @@ extern "C" {
 /* resampling scheme (vae_imputation.py:646-674) and method (:291-298) */
 #define CS_RS_GR 0
 #define CS_RS_GLR 1
+#define CS_RS_LR 2 /* lr_resampling, vae_imputation.py:310-333 */
+#define CS_RS_IR 3 /* ir_resampling, vae_imputation.py:460-482 */
 #define CS_RM_MULTINOMIAL 0
 #define CS_RM_SYSTEMATIC 1
 
@@ -123,7 +125,7 @@ typedef struct {
 
 /* ---------------------------------------------------------------------------------------
  * LAIR iteration = importance_resampling_gibbs_iteration (vae_imputation.py:484-726) for
- * weighting in {dmis, dmis_within_groups, smis}, scheme in {gr, glr}, method in
+ * weighting in {dmis, dmis_within_groups, smis}, scheme in {gr, glr, lr, ir}, method in
  * {multinomial, systematic}, with R prior-replenishing proposals.  K' = K + R.
  */
 typedef struct {
@@ -154,7 +156,7 @@ typedef struct {
   float* gen;          /* [I,B,K',2,D] generator mean and scale; Bernoulli: [I,B,K',D] logits */
   float* gen_ll;       /* [I,B,K'] masked log-likelihood of X under each proposal */
   float* log_w;        /* [I,B,K'] */
-  float* norm_log_w;   /* [B,I*K'] (gr '(i k)'; glr '(g i c)') */
+  float* norm_log_w;   /* [B,I*K'] (gr '(i k)'; glr '(g i c)'; lr '(k i)'; ir: the log-weights, '(i k)') */
   int64_t* idx;        /* [B,K'] source proposal (flattened i*K'+k') of output slot */
   float* ess;          /* [B] */
   float* tess;         /* [B] ESS of the transformed weights */
@@ -163,6 +165,10 @@ typedef struct {
   int64_t* idx2;            /* optional [B,K'] indices of that second resampling */
   const float* clip_min;    /* optional [D] (test_step_vae_sampling.py:1942-1950) */
   const float* clip_max;
+  /* lr / ir with the multinomial method draw ONE index per chain: torch.multinomial(p, 1) is
+   * argmax(p / e) with e ~ Exp(1) per candidate; injected e[B,K',I] (NULL -> counter RNG) */
+  const float* e_res;
+  const float* e_res2;
 } cs_lair_bufs;
 
 /* Tempering and annealing of proposal parameters, in place on q[B,K',2,Zd] rows k < K:
@@ -175,6 +181,11 @@ typedef struct {
  * M[B,D] is only read when anneal != CS_ANNEAL_NONE. */
 int cs_proposal_transform(float* q, const uint8_t* M, int64_t B, int32_t K, int32_t Kp, int32_t Zd, int32_t D,
                           int32_t latent_dist, int32_t prior, float temperature, int32_t anneal, void* stream);
+
+/* q[B,K',2,Zd] = the prior as the proposal of every chain (loc 0, scale 1; Beta(1,1) for the
+ * uniform prior): standard_importance_resampling (vae_imputation.py:920-930) is
+ * cs_prior_proposals + cs_lair_decode + cs_lair_resample_impute. */
+int cs_prior_proposals(float* q, int64_t B, int32_t Kp, int32_t Zd, int32_t latent_dist, void* stream);
 
 /* encoder forward + distribution parameterisation: q[b,k,:] for k < K
  * (vae_imputation.py:551 + vae.py:214-219), then cs_proposal_transform when the configuration asks

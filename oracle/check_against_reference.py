@@ -105,6 +105,8 @@ def case_lair(ns, name, *, B, K, R, I, D, Zd, H, nb_enc, nb_dec, seed, scheme="g
         ent = tape.entries[n0:]
         kinds = [k for k, _ in ent]
         res_kind = "multinomial" if method == "multinomial" else "rand"
+        if method == "multinomial" and scheme in ("lr", "ir"):
+            res_kind = "exponential"   # one index per chain: ATen's single-sample multinomial
         expect = ["normal", res_kind] + ([res_kind] if resampled_latents else []) + ["normal"]
         assert kinds == expect, kinds
         draws = {"eps_z": torch.from_numpy(ent[0][1]), "u_res": torch.from_numpy(ent[1][1]),
@@ -237,6 +239,68 @@ def case_pseudo_gibbs(ns, name, *, B, K, D, Zd, H, seed, T, clip):
     print(f"[ok] {name}")
 
 
+def case_ir_sampler(ns, name, *, B, K, I, D, Zd, H, seed, T, scheme="gr", weighting="dmis", method="multinomial",
+                    cluster=None, n_final=None):
+    """TestVAEImportanceResampling (sampler + the final resampling of on_test_batch_end)."""
+    import tempfile, types
+    from oracle import cs_oracle_samplers as S
+    enc = O.make_resfc_weights(D, 2 * Zd, 1, H, seed)
+    dec = O.make_resfc_weights(Zd, 2 * D, 1, H, seed + 1)
+    vae = ref_vae(ns, enc, dec)
+    X, M = make_inputs(B, K, D, seed + 2)
+    X_true = X[:, 0].clone()
+    tester = ns.test_step.TestVAEImportanceResampling(
+        num_iterations=T, num_imp_samples=I, weighting_scheme=weighting, resampling_scheme=scheme,
+        resampling_method=method, glr_cluster_size=cluster, resample_final_imps_num_samples=n_final,
+        num_copies=K, **BASE_KW)
+    tester.set_model(vae)
+    tmp = tempfile.mkdtemp()
+    tester.logger = types.SimpleNamespace(experiment=types.SimpleNamespace(get_logdir=lambda: tmp))
+    batch = (X_true, M[:, 0], torch.arange(B))
+    tape = DrawTape(seed + 3)
+    ref_out = []
+    with torch.no_grad(), tape.recording():
+        tester.on_test_batch_start(batch, 0, 0)
+        for o in tester.sampler(X.clone(), M):
+            ref_out.append({k: (v.clone() if torch.is_tensor(v) else np.array(v)) for k, v in o.items()})
+        tester.on_test_batch_end(None, batch, 0, 0)
+    final = dict(np.load(os.path.join(tmp, "imputations_0.npz")))
+    src = S.TapeSource(tape.entries)
+    ora = list(S.ir_sampler(dec, X.clone(), M, src, num_iterations=T, num_imp_samples=I, weighting_scheme=weighting,
+                            resampling_scheme=scheme, resampling_method=method, glr_cluster_size=cluster))
+    for t, (a, r) in enumerate(zip(ora, ref_out)):
+        assert torch.equal(a["X"], r["X"]), f"X[{t}] not bitwise equal"
+        close(a["is_ess_standard"], r["is_ess_standard"], "ess")
+        close(a["perplexity_standard"], r["perplexity_standard"], "perplexity")
+    idx, Zf, imps = S.lair_final_resample(dec, [a["Z_prop"] for a in ora], [a["log_weights"] for a in ora],
+                                          X_true, M, src, num_samples=n_final)
+    assert src.pos == len(tape.entries)
+    close(imps.unsqueeze(0), final["imputations"], "final imputations")
+    fx = dict(flat_weights("enc", enc)); fx.update(flat_weights("dec", dec))
+    fx.update(S.tape_to_npz_dict(tape.entries))
+    fx.update(X0=X.numpy(), M=M.numpy(), X_true=X_true.numpy(),
+              cfg=np.array([B, K, I, D, Zd, H, T, cluster or 0, n_final or 0], dtype=np.int64),
+              scheme=np.array(scheme), weighting=np.array(weighting), method=np.array(method),
+              X_seq=np.stack([r["X"].numpy() for r in ref_out]),
+              is_ess=np.array([float(r["is_ess_standard"]) for r in ref_out], dtype=np.float32),
+              perplexity=np.array([float(r["perplexity_standard"]) for r in ref_out], dtype=np.float32),
+              final_imputations=final["imputations"], final_idx=idx.numpy())
+    np.savez_compressed(os.path.join(GOLDEN, f"{name}.npz"), **fx)
+    print(f"[ok] {name}")
+
+
+def check_single_sample_multinomial():
+    """The tape's restatement of ATen's single-sample multinomial equals the real call."""
+    from oracle.ref_harness import multinomial_single_from_exponentials
+    p = torch.softmax(torch.randn(50, 7, generator=torch.Generator().manual_seed(1)), -1)
+    g = torch.Generator().manual_seed(2)
+    real = torch.multinomial(p, 1, True, generator=g)
+    g = torch.Generator().manual_seed(2)
+    e = torch.empty_like(p).exponential_(1, generator=g)
+    assert torch.equal(real, multinomial_single_from_exponentials(p, e))
+    print("[ok] single-sample multinomial = argmax(p / Exp(1))")
+
+
 def case_lair_sampler(ns, name, *, B, K, R, D, Zd, H, seed, T, n_final=None, freq=1):
     import tempfile, types
     from oracle import cs_oracle_samplers as S
@@ -331,6 +395,20 @@ def main():
                nkpc=4, cluster=5, R=5)
     case_acmwg(ns, "acmwg_pg_warmup", B=4, K=3, D=7, Zd=3, H=64, seed=808, warmup="pseudo_gibbs", W=3, T=10, p=0.05)
     case_acmwg(ns, "acmwg_nowarmup_noprior", B=4, K=2, D=6, Zd=3, H=64, seed=909, warmup="none", W=0, T=8, p=0.0)
+    check_single_sample_multinomial()
+    case_lair(ns, "lair_lr_mult", B=5, K=3, R=1, I=4, D=9, Zd=4, H=64, nb_enc=1, nb_dec=1, seed=464, scheme="lr",
+              weighting="smis", resampled_latents=True)
+    case_lair(ns, "lair_lr_syst", B=5, K=4, R=0, I=3, D=9, Zd=4, H=64, nb_enc=1, nb_dec=1, seed=474, scheme="lr",
+              method="systematic")
+    case_lair(ns, "lair_ir_mult", B=5, K=3, R=0, I=3, D=9, Zd=4, H=64, nb_enc=1, nb_dec=1, seed=484, scheme="ir")
+    case_lair(ns, "lair_ir_mult_i6", B=4, K=3, R=0, I=6, D=8, Zd=4, H=64, nb_enc=1, nb_dec=1, seed=494, scheme="ir",
+              weighting="smis")
+    case_lair(ns, "lair_ir_syst", B=4, K=4, R=0, I=4, D=8, Zd=4, H=64, nb_enc=1, nb_dec=1, seed=504, scheme="ir",
+              method="systematic")
+    case_ir_sampler(ns, "ir_sampler_gr", B=4, K=3, I=2, D=8, Zd=4, H=64, seed=514, T=4)
+    case_ir_sampler(ns, "ir_sampler_ir_smis", B=3, K=4, I=4, D=8, Zd=4, H=64, seed=524, T=3, scheme="ir",
+                    weighting="smis", n_final=5)
+    case_ir_sampler(ns, "ir_sampler_lr", B=3, K=2, I=5, D=7, Zd=3, H=64, seed=534, T=3, scheme="lr")
     case_lair(ns, "lair_tempered_annealed", B=6, K=4, R=1, I=1, D=11, Zd=5, H=64, nb_enc=1, nb_dec=1, seed=414,
               temperature=1.3, anneal="linear")
     case_lair(ns, "lair_annealed_025_normal", B=5, K=3, R=0, I=2, D=9, Zd=4, H=64, nb_enc=1, nb_dec=1, seed=424,

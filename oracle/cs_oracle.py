@@ -23,6 +23,8 @@ Reference locations restated here (paths relative to the reference root):
   * DM-MIS log-weights                  irwg/utils/weights.py:37-85
   * grouped DM-MIS                      irwg/sampling/vae_imputation.py:380-458
   * gr / glr resampling                 irwg/sampling/vae_imputation.py:284-308,335-378
+  * lr / ir resampling                  irwg/sampling/vae_imputation.py:310-333,460-482,730-738
+  * standard importance resampling      irwg/sampling/vae_imputation.py:904-998
   * systematic resampling               irwg/sampling/vae_imputation.py:804-834
   * LAIR iteration                      irwg/sampling/vae_imputation.py:484-726
   * pseudo-Gibbs iteration              irwg/sampling/vae_imputation.py:19-45
@@ -394,6 +396,48 @@ def glr_resample(log_w, u, cluster_size, method="multinomial"):
     return idx, glob_out, nlw.reshape(B, G * I * c)
 
 
+def single_indices(probs, e):
+    """torch.multinomial(probs[rows,S], 1, replacement=True) with its Exp(1) variates e[rows,S]
+    made explicit: argmax(probs / e) (ATen's single-sample path)."""
+    return torch.argmax(probs.to(torch.float32) / torch.as_tensor(e, dtype=torch.float32), dim=-1)
+
+
+def lr_resample(log_w, draw, method="multinomial"):
+    """Local resampling (vae_imputation.py:310-333): chain k draws one of its I importance samples.
+    ``draw``: Exp(1) variates [B*K, I] (multinomial) or uniforms [B,K,1] (systematic).  Returns
+    idx[B,K] in [0,I), the flattened '(i k)' source of every output slot, and
+    norm_log_weights[B, K*I] ('(k i)' order)."""
+    I, B, K = log_w.shape
+    lw = log_w.permute(1, 2, 0)                                # b k i
+    if method == "multinomial":
+        idx = single_indices(categorical_probs(lw).reshape(B * K, I), draw).reshape(B, K)
+    elif method == "systematic":
+        idx = systematic_indices(lw, torch.as_tensor(draw).reshape(B, K, 1), 1)[..., 0]
+    else:
+        raise NotImplementedError(method)
+    glob = idx * K + torch.arange(K)[None, :]
+    nlw = lw - lw.logsumexp(dim=-1, keepdim=True)
+    return idx, glob, nlw.reshape(B, K * I)
+
+
+def ir_resample(log_w, draw, method="multinomial"):
+    """Independent resampling (vae_imputation.py:460-482 with select_gen_params_for_ir :730-738).
+    The '(i k)' axis of an example is cut into K rows of I consecutive entries (a plain reshape);
+    row r draws one of its entries, output slot r takes flattened proposal r*I + idx.  The
+    "normalised" log-weights it returns are the log-weights themselves, '(i k)' order."""
+    I, B, K = log_w.shape
+    flat = log_w.permute(1, 0, 2).reshape(B, I * K)
+    lw = flat.reshape(B, K, I)
+    if method == "multinomial":
+        idx = single_indices(categorical_probs(lw).reshape(B * K, I), draw).reshape(B, K)
+    elif method == "systematic":
+        idx = systematic_indices(lw, torch.as_tensor(draw).reshape(B, K, 1), 1)[..., 0]
+    else:
+        raise NotImplementedError(method)
+    glob = torch.arange(K)[None, :] * I + idx
+    return idx, glob, flat
+
+
 # --------------------------------------------------------------------------------------
 # LAIR iteration
 # --------------------------------------------------------------------------------------
@@ -403,8 +447,11 @@ def lair_iteration(enc, dec, X, M, draws, *, num_imp_samples=1, weighting="dmis"
                    latent_dist="normal_with_eps", gen_dist="normal_with_eps",
                    return_resampled_latents=False, weight_alpha=None,
                    encoder=None, decoder=None, prior="std_normal",
-                   var_proposal_temperature=None, var_proposal_anneal_type_to_prior=None):
-    """One LAIR step (vae_imputation.py:484-726) with injected draws.  For latent_dist='beta'
+                   var_proposal_temperature=None, var_proposal_anneal_type_to_prior=None,
+                   prior_proposals=False):
+    """One LAIR step (vae_imputation.py:484-726) with injected draws.  ``prior_proposals``:
+    standard_importance_resampling instead (:904-998) -- no encoder, every chain proposes from the
+    prior (N(0,1); the uniform prior as Uniform(0, 1+1e-8), 'eps_z' then holds torch.rand draws).  For latent_dist='beta'
     'eps_z' holds the Beta samples themselves (torch draws them by rejection sampling).
 
     X[B,K,D] float32, M[B,1,D] bool.  draws: 'eps_z'[I,B,K',Zd], 'u_res' (float64
@@ -420,7 +467,28 @@ def lair_iteration(enc, dec, X, M, draws, *, num_imp_samples=1, weighting="dmis"
     Mf = M  # bool [B,1,D]
     out = {}
 
-    var_params = encoder(X)                                   # [B,K,2Zd]
+    if prior_proposals:
+        assert R == 0
+        Zd0 = net_input_dim(dec)
+        if prior == "uniform":
+            return _standard_ir_uniform(dec, X, M, draws, I, weighting, resampling_scheme, resampling_method,
+                                        glr_cluster_size, gen_dist, weight_alpha, decoder)
+        # torch.ones(shape) * prior.mean / prior.scale (:923-924): loc 0, scale exactly 1
+        q_loc_p, q_scale_p = torch.zeros(B, K, Zd0), torch.ones(B, K, Zd0)
+        latent_dist = "normal"
+    var_params = None if prior_proposals else encoder(X)      # [B,K,2Zd]
+    if prior_proposals:
+        Zd = Zd0
+        Xp = X
+        q_loc, q_scale = q_loc_p, q_scale_p
+        Kp = K
+        Z = q_loc + q_scale * draws["eps_z"]
+        gen_params = decoder(Z)
+        log_w, gl, pl, ql = lair_log_weights(Xp, Mf, Z, q_loc, q_scale, gen_params, gen_dist,
+                                             weighting, glr_cluster_size, latent_dist, prior)
+        return _lair_finish(out, X, Mf, Z, gen_params, log_w, gl, pl, ql, q_loc, q_scale, var_params, draws, I, K, Kp,
+                            resampling_scheme, resampling_method, glr_cluster_size, gen_dist, weight_alpha,
+                            return_resampled_latents)
     var_params = transform_proposal_params(var_params, M, latent_dist, var_proposal_temperature,
                                            var_proposal_anneal_type_to_prior, prior)   # :553-561
     Zd = var_params.shape[-1] // 2
@@ -440,6 +508,17 @@ def lair_iteration(enc, dec, X, M, draws, *, num_imp_samples=1, weighting="dmis"
     gen_params = decoder(Z)                                   # [I,B,K',P]
     log_w, gl, pl, ql = lair_log_weights(Xp, Mf, Z, q_loc, q_scale, gen_params, gen_dist,
                                          weighting, glr_cluster_size, latent_dist, prior)
+    return _lair_finish(out, X, Mf, Z, gen_params, log_w, gl, pl, ql, q_loc, q_scale, var_params, draws, I, K, Kp,
+                        resampling_scheme, resampling_method, glr_cluster_size, gen_dist, weight_alpha,
+                        return_resampled_latents)
+
+
+def _lair_finish(out, X, Mf, Z, gen_params, log_w, gl, pl, ql, q_loc, q_scale, var_params, draws, I, K, Kp,
+                 resampling_scheme, resampling_method, glr_cluster_size, gen_dist, weight_alpha,
+                 return_resampled_latents):
+    """Resampling, sampling of the missing values, imputation and the ESS / perplexity statistics
+    (vae_imputation.py:642-726), shared by the LAIR iteration and standard importance resampling."""
+    B = X.shape[0]
     t_log_w = log_w if weight_alpha is None else log_w * weight_alpha
 
     def resample(u):
@@ -449,6 +528,10 @@ def lair_iteration(enc, dec, X, M, draws, *, num_imp_samples=1, weighting="dmis"
         if resampling_scheme == "glr":
             loc_idx, glob, nlw = glr_resample(t_log_w, u, glr_cluster_size, resampling_method)
             return loc_idx, glob, nlw
+        if resampling_scheme == "lr":
+            return lr_resample(t_log_w, u, resampling_method)
+        if resampling_scheme == "ir":
+            return ir_resample(t_log_w, u, resampling_method)
         raise NotImplementedError(resampling_scheme)
 
     idx_raw, idx_glob, norm_log_w = resample(draws["u_res"])
@@ -477,6 +560,28 @@ def lair_iteration(enc, dec, X, M, draws, *, num_imp_samples=1, weighting="dmis"
                     mix_logprob=ql, idx=idx_raw, idx_global=idx_glob, mis_params=mis_params,
                     X_m=X_m, latents_resampled=latents_resampled))
     return out
+
+
+def _standard_ir_uniform(dec, X, M, draws, I, weighting, scheme, method, cluster, gen_dist, weight_alpha, decoder):
+    """standard_importance_resampling under the uniform prior (:925-928): proposals
+    Uniform(0, 1+1e-8) for every chain; sample = rand*(high-low)+low."""
+    B, K, D = X.shape
+    low, high = torch.tensor(0.), torch.tensor(1. + 1e-8)
+    Z = low + draws["eps_z"] * (high - low)
+    gen_params = decoder(Z)
+    gl = (gen_log_prob(X, gen_params, gen_dist) * M).sum(-1)
+    pl = uniform_prior_log_prob(Z).sum(-1)
+    comp = uniform_prior_log_prob(Z).sum(-1)          # every component is the same uniform density
+    if weighting == "dmis":
+        ql = torch.logsumexp(comp.unsqueeze(-1).expand(*comp.shape, K), dim=-1) - torch.log(torch.tensor(K))
+    elif weighting == "smis":
+        ql = comp
+    else:
+        raise NotImplementedError(weighting)
+    log_w = gl + pl - ql
+    Zd = Z.shape[-1]
+    return _lair_finish({}, X, M, Z, gen_params, log_w, gl, pl, ql, torch.ones(B, K, Zd), torch.ones(B, K, Zd), None,
+                        draws, I, K, K, scheme, method, cluster, gen_dist, weight_alpha, False)
 
 
 def pseudo_gibbs_iteration(enc, dec, X, M, draws, *, latent_dist="normal_with_eps",

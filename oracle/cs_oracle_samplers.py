@@ -48,6 +48,10 @@ class TapeSource:
     def uniform64(self, *shape):
         return self._take(("multinomial",), shape)
 
+    def exponential(self, *shape):
+        """Exp(1) variates of a single-sample multinomial (argmax(p / e))."""
+        return self._take(("exponential",), shape)
+
     def randint(self, high):
         """One integer in [0, high) per call, as the reference's history queue draws them.
         Consecutive single draws may be stored merged as one 'randint_block' entry."""
@@ -109,6 +113,9 @@ class SeededSource:
     def uniform64(self, *shape):
         return torch.rand(*shape, generator=self.g, dtype=torch.float64)
 
+    def exponential(self, *shape):
+        return torch.empty(*shape).exponential_(1, generator=self.g)
+
     def randint(self, high):
         return int(torch.randint(0, int(high), (1,), generator=self.g)[0])
 
@@ -127,6 +134,8 @@ def _lair_draws(src, I, B, K, R, D, Zd, *, scheme, method, cluster, gen_dist, se
     G = Kp // cluster if scheme == "glr" else 1
 
     def res():
+        if scheme in ("lr", "ir"):
+            return src.exponential(B * Kp, I) if method == "multinomial" else src.uniform(B, Kp, 1)
         if method == "multinomial":
             return src.uniform64(B * G, Kp // G)
         return src.uniform(B, 1) if scheme == "gr" else src.uniform(B, G, 1)
@@ -352,3 +361,21 @@ def pseudo_gibbs_sampler(enc, dec, X, M, src, *, num_iterations, clip_imputation
         X, Z = O.pseudo_gibbs_iteration(enc, dec, X, M, draws, latent_dist=latent_dist, gen_dist=gen_dist,
                                         clip_min=clip_min, clip_max=clip_max)
         yield {"X": X, "Z": Z}
+
+
+def ir_sampler(dec, X, M, src, *, num_iterations, num_imp_samples, weighting_scheme="dmis", resampling_scheme="gr",
+               resampling_method="multinomial", glr_cluster_size=None, gen_dist="normal_with_eps"):
+    """TestVAEImportanceResampling.sampler (test_step_vae_sampling.py:2105-2131): importance
+    resampling with the prior as the proposal.  Yields the reference's dict plus 'Z_prop' and
+    'log_weights' (what the class stores for its final resampling)."""
+    B, K, D = X.shape
+    Zd = O.net_input_dim(dec)
+    for t in range(num_iterations):
+        draws = _lair_draws(src, num_imp_samples, B, K, 0, D, Zd, scheme=resampling_scheme, method=resampling_method,
+                            cluster=glr_cluster_size, gen_dist=gen_dist, second=False)
+        o = O.lair_iteration(None, dec, X, M, draws, num_imp_samples=num_imp_samples, weighting=weighting_scheme,
+                             resampling_scheme=resampling_scheme, resampling_method=resampling_method,
+                             glr_cluster_size=glr_cluster_size, gen_dist=gen_dist, prior_proposals=True)
+        X = o["X_new"]
+        yield {"X": X, "is_ess_standard": o["ess"].mean(), "is_ess_not_reduced": o["ess"],
+               "perplexity_standard": o["perplexity"].mean(), "Z_prop": o["Z_imp"], "log_weights": o["log_weights"]}

@@ -148,6 +148,8 @@ class DrawTape:
       * ``randn``        the standard-normal tensor itself
       * ``multinomial``  float64 uniforms ``u[rows, n]`` such that the returned index is the
                          left bisection of the row CDF (n > 1, replacement=True)
+      * ``exponential``  float32 Exp(1) variates ``e[rows, S]`` of a single-sample multinomial:
+                         ATen returns ``argmax(probs / e)`` when one sample is drawn
       * ``rand`` / ``rand_like``  the uniforms
       * ``bernoulli``    float32 uniforms u; result is ``u < p``
       * ``randint``      the integers drawn
@@ -211,6 +213,10 @@ class DrawTape:
 
         def multinomial(probs, num_samples, replacement=False, *, generator=None):
             assert replacement and probs.dim() == 2
+            if num_samples == 1:
+                e = torch.empty(probs.shape, dtype=torch.float32).exponential_(1, generator=tape.gen)
+                tape._rec("exponential", e)
+                return multinomial_single_from_exponentials(probs, e)
             u = orig["rand"]((probs.shape[0], num_samples), generator=tape.gen, dtype=torch.float64)
             tape._rec("multinomial", u)
             return multinomial_from_uniforms(probs, u)
@@ -258,3 +264,12 @@ def multinomial_from_uniforms(probs, u):
         cum[S - 1] = np.float32(1.0)
         out[r] = np.searchsorted(cum.astype(np.float64), u[r], side="left")
     return torch.from_numpy(out)
+
+
+def multinomial_single_from_exponentials(probs, e):
+    """torch.multinomial(probs[rows,S], 1, replacement=True) on CPU with its Exp(1) variates made
+    explicit: ATen's single-sample path divides the probabilities by the variates and returns the
+    argmax.  Equality with the real call under a shared generator is asserted in
+    ``oracle/check_against_reference.py``."""
+    q = probs.detach().cpu().to(torch.float32) / e
+    return torch.argmax(q, dim=-1, keepdim=True)

@@ -19,7 +19,7 @@ pytestmark = pytest.mark.gpu
 
 LAIR_CASES = ["lair_gr_mult_small", "lair_gr_mult_i2_lat", "lair_gr_mult_noreplenish", "lair_gr_syst",
               "lair_glr_groups", "lair_miniboone_shape", "lair_tempered_annealed", "lair_annealed_025_normal",
-              "lair_tempered"]
+              "lair_tempered", "lair_lr_mult", "lair_lr_syst", "lair_ir_mult", "lair_ir_mult_i6", "lair_ir_syst"]
 
 
 @pytest.fixture(scope="module")

@@ -114,6 +114,33 @@ def test_lair_sampler_and_final_resampling_match_reference_golden(name):
     assert_close(imps, fx["final_imputations"], "final imputations")
 
 
+@pytest.mark.parametrize("name", ["ir_sampler_gr", "ir_sampler_ir_smis", "ir_sampler_lr"])
+def test_importance_resampling_sampler_matches_reference_golden(name):
+    """TestVAEImportanceResampling: prior proposals, gr / lr / ir resampling, final resampling."""
+    from vae_conditional_sampling_amd.sampling.test_step_vae_sampling import TestVAEImportanceResampling as Sampler
+    fx = load_golden(name)
+    B, K, I, D, Zd, H, T, cluster, n_final = [int(v) for v in fx["cfg"]]
+    model = make_model(weights_from_fixture(fx, "enc"), weights_from_fixture(fx, "dec"))
+    s = Sampler(num_iterations=T, num_imp_samples=I, weighting_scheme=str(fx["weighting"]),
+                resampling_scheme=str(fx["scheme"]), resampling_method=str(fx["method"]),
+                glr_cluster_size=cluster or None, resample_final_imps_num_samples=n_final or None, num_copies=K,
+                **BASE_KW)
+    s.set_model(model)
+    s.on_test_start()
+    s.draw_source = tape_source(fx)
+    X = torch.from_numpy(fx["X0"]).cuda()
+    M = torch.from_numpy(fx["M"]).cuda()
+    s.on_test_batch_start(None, 0)
+    for t, o in enumerate(s.sampler(X, M)):
+        assert_close(o["X"], fx["X_seq"][t], f"X[{t}]")
+        assert abs(float(o["is_ess_standard"]) - float(fx["is_ess"][t])) < 1e-4 * float(fx["is_ess"][t])
+        assert abs(float(o["perplexity_standard"]) - float(fx["perplexity"][t])) < 1e-4 * float(fx["perplexity"][t])
+    imps, Zf, idx = s.final_resampling(torch.from_numpy(fx["X_true"]), M)
+    assert s.draw_source.pos == len(s.draw_source.entries)
+    assert np.array_equal(idx.cpu().numpy(), fx["final_idx"]), "final resampling indices differ"
+    assert_close(imps, fx["final_imputations"], "final imputations")
+
+
 def test_imputation_diagnostics_match_reference_golden():
     """RMSE / MAE / latent-Wasserstein kernels against the reference's imputation_metrics functions."""
     from vae_conditional_sampling_amd.sampling import imputation_metrics as IM

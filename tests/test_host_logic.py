@@ -48,7 +48,7 @@ def test_unsupported_options_raise_not_implemented():
     s.skip_unimplemented_diagnostics = True
     s.on_test_start()
     X = torch.zeros(2, 2, 3); M = torch.ones(2, 1, 3, dtype=torch.bool)
-    for bad in (dict(resampling_scheme="lr"), dict(resampling_scheme="ir"), dict(weighting="nope"),
+    for bad in (dict(resampling_scheme="rr"), dict(weighting="nope"),
                 dict(resampling_method="residual"), dict(use_historical_proposals=True),
                 dict(var_proposal_anneal_type_to_prior="quadratic"), dict(accept_reject_xm=True)):
         with pytest.raises(NotImplementedError):

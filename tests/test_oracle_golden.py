@@ -15,7 +15,7 @@ from tests.helpers import assert_close, load_golden, weights_from_fixture
 
 LAIR_CASES = ["lair_gr_mult_small", "lair_gr_mult_i2_lat", "lair_gr_mult_noreplenish", "lair_gr_syst",
               "lair_glr_groups", "lair_miniboone_shape", "lair_tempered_annealed", "lair_annealed_025_normal",
-              "lair_tempered"]
+              "lair_tempered", "lair_lr_mult", "lair_lr_syst", "lair_ir_mult", "lair_ir_mult_i6", "lair_ir_syst"]
 
 
 @pytest.mark.parametrize("name", LAIR_CASES)
@@ -101,5 +101,25 @@ def test_oracle_lair_sampler_final(name):
         assert_close(o["X"], fx["X_seq"][t], f"X[{t}]")
     idx, Zf, imps = S.lair_final_resample(dec, [o["Z_prop"] for o in outs], [o["log_weights"] for o in outs],
                                           torch.from_numpy(fx["X_true"]), M, src, num_samples=n_final or None)
+    assert np.array_equal(idx.numpy(), fx["final_idx"])
+    assert_close(imps.unsqueeze(0), fx["final_imputations"], "final imputations")
+
+
+@pytest.mark.parametrize("name", ["ir_sampler_gr", "ir_sampler_ir_smis", "ir_sampler_lr"])
+def test_oracle_importance_resampling_sampler(name):
+    fx = load_golden(name)
+    B, K, I, D, Zd, H, T, cluster, n_final = [int(v) for v in fx["cfg"]]
+    dec = weights_from_fixture(fx, "dec")
+    src = S.TapeSource(S.tape_from_npz_dict(fx))
+    M = torch.from_numpy(fx["M"])
+    outs = list(S.ir_sampler(dec, torch.from_numpy(fx["X0"]), M, src, num_iterations=T, num_imp_samples=I,
+                             weighting_scheme=str(fx["weighting"]), resampling_scheme=str(fx["scheme"]),
+                             resampling_method=str(fx["method"]), glr_cluster_size=cluster or None))
+    for t, o in enumerate(outs):
+        assert_close(o["X"], fx["X_seq"][t], f"X[{t}]")
+        assert abs(float(o["is_ess_standard"]) - float(fx["is_ess"][t])) < 1e-4 * float(fx["is_ess"][t])
+    idx, Zf, imps = S.lair_final_resample(dec, [o["Z_prop"] for o in outs], [o["log_weights"] for o in outs],
+                                          torch.from_numpy(fx["X_true"]), M, src, num_samples=n_final or None)
+    assert src.pos == len(src.entries)
     assert np.array_equal(idx.numpy(), fx["final_idx"])
     assert_close(imps.unsqueeze(0), fx["final_imputations"], "final imputations")

@@ -113,3 +113,36 @@ def test_multinomial_restatement_matches_torch_multinomial():
         u = torch.rand(rows, n, dtype=torch.float64, generator=g2)
         assert torch.equal(O.multinomial_indices(p, u.numpy()), ref)
         assert np.array_equal(c_binding.multinomial_left(L, p.numpy(), u.numpy()), ref.numpy())
+
+
+def test_independent_resampling_indexing_known_answers():
+    """The reference's two checks of select_gen_params_for_ir (vae_imputation.py:1004-1057): with
+    I == K output (b, k) is X[k, b, idx[b, k]]; with I == 2K it is entry idx[b, k] of the chain-k row
+    of '(i i2) b k p -> i b (i2 k) p'.  The oracle's flattened-source rule (slot k takes proposal
+    k*I + idx of the '(i k)' axis) must give the same selections for the reference's index tables."""
+    B, P, K = 6, 4, 5
+    tables = {5: [[0, 1, 3, 2, 3], [4, 1, 1, 1, 1], [0, 0, 1, 2, 0], [0, 1, 3, 1, 1], [2, 2, 4, 2, 3], [1, 0, 3, 2, 0]],
+              10: [[0, 8, 5, 2, 9], [4, 1, 1, 1, 1], [0, 0, 1, 2, 5], [0, 1, 3, 7, 1], [2, 8, 4, 2, 3], [1, 6, 6, 2, 0]]}
+    for I, table in tables.items():
+        idx = torch.tensor(table)
+        X = torch.randn(I, B, K, P, generator=torch.Generator().manual_seed(I))
+        glob = torch.arange(K)[None, :] * I + idx                    # the rule of cs_oracle.ir_resample
+        picked = O.gather_gr(X, glob)                                # [B,K,P]
+        if I == K:
+            expect = torch.stack([torch.stack([X[k, b, idx[b, k]] for k in range(K)]) for b in range(B)])
+        else:
+            i2 = I // K
+            Xr = X.reshape(K, i2, B, K, P).permute(0, 2, 1, 3, 4).reshape(K, B, i2 * K, P)
+            expect = torch.stack([torch.stack([Xr[k, b, idx[b, k]] for k in range(K)]) for b in range(B)])
+        assert torch.equal(picked, expect)
+
+
+def test_single_sample_multinomial_restatement_matches_torch():
+    """torch.multinomial(p, 1, replacement=True) on CPU = argmax(p / Exp(1)) with the variates drawn
+    by exponential_ from the same generator (lr / ir resampling draw one index per chain)."""
+    p = torch.softmax(torch.randn(40, 9, generator=torch.Generator().manual_seed(3)), -1)
+    g = torch.Generator().manual_seed(4)
+    real = torch.multinomial(p, 1, True, generator=g)[:, 0]
+    g = torch.Generator().manual_seed(4)
+    e = torch.empty_like(p).exponential_(1, generator=g)
+    assert torch.equal(real, O.single_indices(p, e))

@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libcsvae.so")
 CS_DIST = {"normal": 0, "normal_with_eps": 1, "bern": 2, "beta": 3}
 CS_PRIOR = {"std_normal": 0, "uniform": 1}
 CS_WEIGHTING = {"dmis": 0, "dmis_within_groups": 1, "smis": 2}
-CS_SCHEME = {"gr": 0, "glr": 1}
+CS_SCHEME = {"gr": 0, "glr": 1, "lr": 2, "ir": 3}
 CS_METHOD = {"multinomial": 0, "systematic": 1}
 CS_ANNEAL = {None: 0, "linear": 1, "linear_0.25": 2}
 
@@ -71,7 +71,7 @@ class cs_lair_cfg(C.Structure):
 
 _LAIR_BUF_FIELDS = ["X", "M", "eps_z", "u_res", "u_res2", "u_sys", "u_sys2", "eps_x", "q", "Z", "gen",
                     "gen_ll", "log_w", "norm_log_w", "idx", "ess", "tess", "perplexity",
-                    "latents_resampled", "idx2", "clip_min", "clip_max"]
+                    "latents_resampled", "idx2", "clip_min", "clip_max", "e_res", "e_res2"]
 
 
 class cs_lair_bufs(C.Structure):
@@ -124,6 +124,7 @@ def lib():
     L.cs_net_create.argtypes = [C.POINTER(cs_layer_desc), i32, vp, i64, i32, i32, i32, C.POINTER(vp)]
     L.cs_mlp_forward.argtypes = [vp, vp, i64, vp, vp]
     L.cs_proposal_transform.argtypes = [vp, vp, i64, i32, i32, i32, i32, i32, i32, C.c_float, i32, vp]
+    L.cs_prior_proposals.argtypes = [vp, i64, i32, i32, i32, vp]
     L.cs_lair_encode.argtypes = [vp, C.POINTER(cs_lair_cfg), C.POINTER(cs_lair_bufs), vp]
     L.cs_lair_decode.argtypes = [vp, C.POINTER(cs_lair_cfg), C.POINTER(cs_lair_bufs), C.POINTER(cs_rng), vp]
     L.cs_lair_resample_impute.argtypes = [C.POINTER(cs_lair_cfg), C.POINTER(cs_lair_bufs), C.POINTER(cs_rng), vp]

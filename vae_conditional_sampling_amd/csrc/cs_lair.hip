@@ -93,15 +93,27 @@ __global__ void __launch_bounds__(64) cs_lair_resample_kernel(const CsResampleAr
   const int base = act ? e_l * S : 0;       // first lane of this example
   const int64_t b = b0 + e_l;
   const int i_s = s / Kp, kp_s = s - i_s * Kp;
-  const int g_s = kp_s % G, cc_s = kp_s / G;
-  const int li_s = i_s * c + cc_s;          // position inside the resampling group, '(i c)' order
+  // Resampling group of this proposal and its position inside the group.  gr / glr / lr: group
+  // kp mod G, members in '(i c)' order (lr: G = K', c = 1, so the group of chain k holds its I
+  // importance samples).  ir: the flattened '(i k)' axis is cut into K' runs of I consecutive
+  // entries (the reference's reshape(B, K, -1), vae_imputation.py:463-464).
+  const bool ir = a.cfg.scheme == CS_RS_IR;
+  const int g_s = ir ? s / I : kp_s % G;
+  const int cc_s = kp_s / G;
+  const int li_s = ir ? s - g_s * I : i_s * c + cc_s;
+  // bit jj: proposal jj of this example is in this lane's group (member order = lane order)
+  unsigned long long gmask = 0;
+  for (int jj = 0; jj < S; ++jj) {
+    const int gj = ir ? jj / I : (jj % Kp) % G;
+    if (gj == g_s) gmask |= 1ull << jj;
+  }
 
   // reductions over the lanes of this example (optionally only its resampling group)
   auto seg_max = [&](float x, bool grouped) {
     float m = -INFINITY;
     for (int jj = 0; jj < S; ++jj) {
       const float v = __shfl(x, base + jj);
-      if (!grouped || (jj % Kp) % G == g_s) m = fmaxf(m, v);
+      if (!grouped || ((gmask >> jj) & 1ull)) m = fmaxf(m, v);
     }
     return m;
   };
@@ -109,7 +121,7 @@ __global__ void __launch_bounds__(64) cs_lair_resample_kernel(const CsResampleAr
     float t = 0.0f;
     for (int jj = 0; jj < S; ++jj) {
       const float v = __shfl(x, base + jj);
-      if (!grouped || (jj % Kp) % G == g_s) t += v;
+      if (!grouped || ((gmask >> jj) & 1ull)) t += v;
     }
     return t;
   };
@@ -194,7 +206,8 @@ __global__ void __launch_bounds__(64) cs_lair_resample_kernel(const CsResampleAr
 
   // ---- resampling within groups ----
   const float nl = tlw - seg_lse(tlw, true);  // normalised log-weight (Categorical.logits)
-  if (act) a.b.norm_log_w[b * S + (int64_t)g_s * (I * c) + li_s] = nl;
+  // ir returns the (transformed) log-weights themselves, in '(i k)' order (vae_imputation.py:479-480)
+  if (act) a.b.norm_log_w[b * S + (ir ? s : g_s * (I * c) + li_s)] = ir ? tlw : nl;
   float p;
   if (a.cfg.method == CS_RM_MULTINOMIAL) {
     // Categorical.probs = softmax(normalised logits)
@@ -210,16 +223,43 @@ __global__ void __launch_bounds__(64) cs_lair_resample_kernel(const CsResampleAr
   float run = 0.0f, cum = 0.0f;
   for (int jj = 0; jj < S; ++jj) {
     const float pj = __shfl(p, base + jj);
-    if ((jj % Kp) % G == g_s) run += pj;
+    if ((gmask >> jj) & 1ull) run += pj;
     if (s == jj) cum = run;
   }
-  const bool last_in_group = (i_s == I - 1) && (cc_s == c - 1);
+  const bool last_in_group = li_s == I * c - 1;
+  // one draw per group (lr, ir): torch.multinomial(p, 1) = argmax(p / Exp(1)), first maximum
+  const bool race = a.cfg.method == CS_RM_MULTINOMIAL && (a.cfg.scheme == CS_RS_LR || ir);
   const unsigned long long ex_mask = (S == 64 ? ~0ull : ((1ull << S) - 1ull)) << base;
 
   const int ndraw_sets = (a.b.latents_resampled != nullptr) ? 2 : 1;
   int* my_idx = l_idx + e_l * 2 * Kp;
   for (int set = 0; set < ndraw_sets; ++set) {
-    if (a.cfg.method == CS_RM_MULTINOMIAL) {
+    if (race) {
+      const float* ein = set == 0 ? a.b.e_res : a.b.e_res2;
+      float v = -INFINITY;
+      if (act) {
+        const int el = g_s * I + li_s;  // element of the [K', I] block of exponentials of example b
+        float ex;
+        if (ein) {
+          ex = ein[b * S + el];
+        } else {
+          uint32_t x[4];
+          cs_philox_block(a.rng, set == 0 ? CS_STREAM_URES : CS_STREAM_URES2, a.rng.row_offset + b, (uint32_t)(el >> 2), x);
+          ex = -logf(1.0f - cs_u01f(x[el & 3]));
+        }
+        v = p / ex;
+      }
+      float best = -INFINITY;
+      int best_li = 0, cnt = 0;
+      for (int jj = 0; jj < S; ++jj) {
+        const float vj = __shfl(v, base + jj);
+        if ((gmask >> jj) & 1ull) {
+          if (vj > best) { best = vj; best_li = cnt; }
+          ++cnt;
+        }
+      }
+      if (act && li_s == 0) my_idx[set * Kp + g_s] = ir ? g_s * I + best_li : best_li * Kp + g_s;
+    } else if (a.cfg.method == CS_RM_MULTINOMIAL) {
       // torch.multinomial: cum / total, last forced to 1, left bisection with float64 uniforms
       float cn = cum / run;
       if (last_in_group) cn = 1.0f;
@@ -256,7 +296,7 @@ __global__ void __launch_bounds__(64) cs_lair_resample_kernel(const CsResampleAr
           int li = __popcll(mask & ex_mask);
           if (li > I * c - 1) li = I * c - 1;  // the reference would index out of bounds here
           const int il = li / c, cl = li - il * c;
-          if (act && s == 0) my_idx[set * Kp + t * G + g] = il * Kp + cl * G + g;
+          if (act && s == 0) my_idx[set * Kp + t * G + g] = ir ? g * I + li : il * Kp + cl * G + g;
         }
       }
     }
@@ -408,6 +448,25 @@ extern "C" int cs_proposal_transform(float* q, const uint8_t* M, int64_t B, int3
   return CS_OK;
 }
 
+// q[b,k] = the prior as a proposal: N(0, 1), or Beta(1, 1) for the uniform prior
+// (standard_importance_resampling, vae_imputation.py:920-930).
+__global__ void __launch_bounds__(256) cs_prior_proposals_kernel(float* q, int64_t n, int Zd, int beta) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t < n) q[t] = (beta || ((t / Zd) & 1)) ? 1.0f : 0.0f;
+}
+
+extern "C" int cs_prior_proposals(float* q, int64_t B, int32_t Kp, int32_t Zd, int32_t latent_dist, void* stream) {
+  CS_REQUIRE(q && B >= 0 && Kp >= 1 && Zd >= 1, "bad argument");
+  CS_REQUIRE(latent_dist == CS_DIST_NORMAL || latent_dist == CS_DIST_NORMAL_WITH_EPS || latent_dist == CS_DIST_BETA,
+             "latent distribution must be normal / normal_with_eps / beta");
+  const int64_t n = B * Kp * 2 * Zd;
+  if (n == 0) return CS_OK;
+  hipLaunchKernelGGL(cs_prior_proposals_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, q,
+                     n, Zd, latent_dist == CS_DIST_BETA ? 1 : 0);
+  CS_HIP(hipGetLastError());
+  return CS_OK;
+}
+
 extern "C" int cs_lair_encode(const cs_mlp_t* enc, const cs_lair_cfg* c, const cs_lair_bufs* b, void* stream) {
   if (int rc = check_cfg(c, b)) return rc;
   if (c->B == 0) return CS_OK;  // empty batch: nothing to do (its tensors have no storage)
@@ -478,8 +537,10 @@ extern "C" int cs_lair_resample_impute(const cs_lair_cfg* c, const cs_lair_bufs*
   } else if (c->scheme == CS_RS_GLR) {
     CS_REQUIRE(c->cluster_size > 1 && a.Kp % c->cluster_size == 0, "glr needs cluster_size > 1 dividing K+R");
     a.c = c->cluster_size; a.G = a.Kp / a.c;
+  } else if (c->scheme == CS_RS_LR || c->scheme == CS_RS_IR) {
+    a.c = 1; a.G = a.Kp;  // one draw per chain among I candidates
   } else {
-    return cs_fail(CS_EUNSUPPORTED, "resampling scheme not implemented (gr, glr only)");
+    return cs_fail(CS_EUNSUPPORTED, "unknown resampling scheme");
   }
   if (c->weighting == CS_W_DMIS) {
     a.mixG = 1; a.mixc = a.Kp;

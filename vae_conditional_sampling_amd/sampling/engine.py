@@ -71,8 +71,9 @@ def lair_cfg(model, ws, *, weighting, scheme, method, cluster_size, weight_alpha
 
 
 def lair_step(model, ws, X, M8, cfg, *, rng=None, draws=None, return_resampled_latents=False,
-              clip_min=None, clip_max=None):
-    """One LAIR iteration in place on ``X`` [B,K,D] (cs_lair_step)."""
+              clip_min=None, clip_max=None, prior_proposals=False):
+    """One LAIR iteration in place on ``X`` [B,K,D] (cs_lair_step).  ``prior_proposals``: every
+    chain proposes from the prior instead of the encoder (standard importance resampling)."""
     draws = draws or {}
     dev = X.device
     g = lambda k, dt: (draws[k].to(dev, dt).contiguous() if draws.get(k) is not None else None)
@@ -81,6 +82,10 @@ def lair_step(model, ws, X, M8, cfg, *, rng=None, draws=None, return_resampled_l
     if systematic:
         keep += [g("u_res", torch.float32), g("u_res2", torch.float32)]
         ud = dict(u_sys=keep[2], u_sys2=keep[3])
+    elif cfg.scheme in (_lib.CS_SCHEME["lr"], _lib.CS_SCHEME["ir"]):
+        # one index per chain: the draws are the Exp(1) variates of torch.multinomial(p, 1)
+        keep += [g("u_res", torch.float32), g("u_res2", torch.float32)]
+        ud = dict(e_res=keep[2], e_res2=keep[3])
     else:
         keep += [g("u_res", torch.float64), g("u_res2", torch.float64)]
         ud = dict(u_res=keep[2], u_res2=keep[3])
@@ -93,10 +98,15 @@ def lair_step(model, ws, X, M8, cfg, *, rng=None, draws=None, return_resampled_l
                           idx2=ws.idx2 if return_resampled_latents else None,
                           clip_min=clip_min, clip_max=clip_max, **ud)
     rng = rng if rng is not None else _lib.make_rng(0)
-    enc = model.var_latent_network.packed()
     dec = model.generator_network.packed()
-    _lib.check(_lib.lib().cs_lair_step(enc.handle, dec.handle, C.byref(cfg), C.byref(bufs), C.byref(rng),
-                                       _lib.current_stream()))
+    L, st = _lib.lib(), _lib.current_stream()
+    if prior_proposals:
+        _lib.check(L.cs_prior_proposals(_lib.ptr(ws.q), ws.B, ws.Kp, ws.Zd, cfg.latent_dist, st))
+        _lib.check(L.cs_lair_decode(dec.handle, C.byref(cfg), C.byref(bufs), C.byref(rng), st))
+        _lib.check(L.cs_lair_resample_impute(C.byref(cfg), C.byref(bufs), C.byref(rng), st))
+        return ws
+    enc = model.var_latent_network.packed()
+    _lib.check(L.cs_lair_step(enc.handle, dec.handle, C.byref(cfg), C.byref(bufs), C.byref(rng), st))
     return ws
 
 

@@ -5,6 +5,8 @@ Counterparts in irwg/sampling/test_step_vae_sampling.py:
   TestVAESamplerBase                                 :102-1000 (the parts LAIR / AC-MWG use)
   TestVAELatentAdaptiveImportanceResampling (LAIR)   :1770-2061
   TestVAEAdaptiveCollapsedMetropolisWithinGibbs      :1457-1768
+  TestVAEPseudoGibbs :1002-1042, TestVAEMetropolisWithinGibbs :1045-1282,
+  TestVAEImportanceResampling :2063-2194            (baselines on the same kernels)
 
 Extensions that do not exist in the reference (all optional):
   * ``rng_seed`` / ``example_offset`` attributes key the counter RNG (global example index, so a
@@ -26,7 +28,8 @@ from .. import _lib
 from ..utils.hparams import HyperparametersMixin
 from . import engine, imputation_metrics
 from .utils import ImputationHistoryQueue_with_restrictedavailability
-from .vae_imputation import importance_resampling_gibbs_iteration, pseudo_gibbs_iteration
+from .vae_imputation import (importance_resampling_gibbs_iteration, pseudo_gibbs_iteration,
+                             standard_importance_resampling)
 
 # diagnostics of the reference's harness that are NOT implemented here (the point-wise RMSE, MAE and
 # latent-Wasserstein metrics are: sampling/imputation_metrics.py)
@@ -313,6 +316,37 @@ class TestVAESamplerBase(HyperparametersMixin):
         return out
 
 
+def _final_resampling(self, proposals, X_true, M, num_samples):
+    """Categorical over all stored proposals of every example, ``n`` draws, decode in one launch,
+    sample and set the observed values (test_step_vae_sampling.py:1991-2032, 2151-2185).
+    ``proposals`` = (Z[T,I,B,K',Zd], log_w[T,I,B,K']) on the device."""
+    import ctypes as C
+    Zp, lw = proposals
+    T, I, B, Kp, Zd = Zp.shape
+    n = T * Kp if num_samples is None else num_samples
+    dev = Zp.device
+    src = self.draw_source
+    u = src.uniform64(B, n).to(dev).contiguous() if src is not None else None
+    cdf = torch.empty(B, T * I * Kp, device=dev)
+    idx = torch.empty(B, n, device=dev, dtype=torch.int64)
+    Zout = torch.empty(B, n, Zd, device=dev)
+    rng = _lib.make_rng(self.rng_seed, 0, self.example_offset)
+    _lib.check(_lib.lib().cs_final_resample(_lib.ptr(lw), _lib.ptr(Zp), T * I, B, Kp, Zd, _lib.ptr(u),
+                                            C.byref(rng), n, _lib.ptr(cdf), _lib.ptr(idx), _lib.ptr(Zout),
+                                            _lib.current_stream()))
+    gen = engine.decode_params(self.model, Zout.reshape(B * n, Zd))
+    D = X_true.shape[-1]
+    Xz = X_true.to(dev, torch.float32).unsqueeze(1).repeat(1, n, 1).contiguous()
+    eps = None
+    if src is not None:
+        bern = self.model.hparams.generator_distribution.name == "bern"
+        chunks = [(src.uniform if bern else src.normal)(B, min(Kp, n - c0), D) for c0 in range(0, n, Kp)]
+        eps = torch.cat(chunks, dim=1)
+    engine.sample_impute(self.model, gen, Xz, engine.mask_u8(M), n, eps=eps, rng=rng,
+                         stream_id=_lib.STREAM_UFINAL, zero_missing=True)
+    return Xz.unsqueeze(0), Zout, idx
+
+
 class TestVAELatentAdaptiveImportanceResampling(TestVAESamplerBase):
     """IRWG sampling, called LAIR (latent-adaptive importance resampling) in the paper."""
 
@@ -391,6 +425,8 @@ class TestVAELatentAdaptiveImportanceResampling(TestVAESamplerBase):
         G = Kp // hp.glr_cluster_size if hp.resampling_scheme == 'glr' else 1
 
         def res():
+            if hp.resampling_scheme in ('lr', 'ir'):  # one index per chain among its I candidates
+                return src.exponential(B * Kp, I) if hp.resampling_method == 'multinomial' else src.uniform(B, Kp, 1)
             if hp.resampling_method == 'multinomial':
                 return src.uniform64(B * G, Kp // G)
             return src.uniform(B, 1) if hp.resampling_scheme == 'gr' else src.uniform(B, G, 1)
@@ -470,32 +506,7 @@ class TestVAELatentAdaptiveImportanceResampling(TestVAESamplerBase):
     def final_resampling(self, X_true, M):
         """Resample the latents across all iterations and decode (:1991-2032).  Returns
         ``(imputations[1,B,n,D], latents[B,n,Zd], idx[B,n])`` as device tensors."""
-        hp = self.hparams
-        Zp, lw = self._proposals
-        T, I, B, Kp, Zd = Zp.shape
-        n = T * Kp if hp.resample_final_imps_num_samples is None else hp.resample_final_imps_num_samples
-        dev = Zp.device
-        src = self.draw_source
-        u = src.uniform64(B, n).to(dev).contiguous() if src is not None else None
-        cdf = torch.empty(B, T * I * Kp, device=dev)
-        idx = torch.empty(B, n, device=dev, dtype=torch.int64)
-        Zout = torch.empty(B, n, Zd, device=dev)
-        import ctypes as C
-        rng = _lib.make_rng(self.rng_seed, 0, self.example_offset)
-        _lib.check(_lib.lib().cs_final_resample(_lib.ptr(lw), _lib.ptr(Zp), T * I, B, Kp, Zd, _lib.ptr(u),
-                                                C.byref(rng), n, _lib.ptr(cdf), _lib.ptr(idx), _lib.ptr(Zout),
-                                                _lib.current_stream()))
-        gen = engine.decode_params(self.model, Zout.reshape(B * n, Zd))
-        D = X_true.shape[-1]
-        Xz = X_true.to(dev, torch.float32).unsqueeze(1).repeat(1, n, 1).contiguous()
-        eps = None
-        if src is not None:
-            bern = self.model.hparams.generator_distribution.name == "bern"
-            chunks = [(src.uniform if bern else src.normal)(B, min(Kp, n - c0), D) for c0 in range(0, n, Kp)]
-            eps = torch.cat(chunks, dim=1)
-        engine.sample_impute(self.model, gen, Xz, engine.mask_u8(M), n, eps=eps, rng=rng,
-                             stream_id=_lib.STREAM_UFINAL, zero_missing=True)
-        return Xz.unsqueeze(0), Zout, idx
+        return _final_resampling(self, self._proposals, X_true, M, self.hparams.resample_final_imps_num_samples)
 
     def on_test_batch_end(self, outputs, batch: Any, batch_idx: int, dataloader_idx: int = 0) -> None:
         super().on_test_batch_end(outputs, batch, batch_idx, dataloader_idx)
@@ -524,6 +535,97 @@ class TestVAELatentAdaptiveImportanceResampling(TestVAESamplerBase):
             np.savez_compressed(os.path.join(self.out_dir, 'is_norm_log_weights.npz'),
                                 is_norm_log_weights=np.concatenate(self.norm_log_weights))
         return out
+
+
+class TestVAEImportanceResampling(TestVAESamplerBase):
+    """IR sampling: importance resampling with the prior as the proposal
+    (test_step_vae_sampling.py:2063-2194).  After the last iteration of a batch the latents of all
+    iterations are resampled and decoded, and ``imputations_{batch}.npz`` is rewritten with them
+    (the reference's on_test_batch_end overwrites the harness's file of the same name)."""
+
+    def __init__(self,
+                 num_iterations: int,
+                 num_imp_samples: int,
+                 weighting_scheme: str,
+                 resampling_scheme: str,
+                 resampling_method: str,
+                 *args,
+                 glr_cluster_size: int = None,
+
+                 resample_final_imps_num_samples: int = None,
+                 **kwargs
+                 ):
+        super().__init__(*args, **kwargs)
+        self.save_hyperparameters()
+
+    @property
+    def max_iterations(self):
+        return self.hparams.num_iterations
+
+    def on_test_batch_start(self, batch: Any, batch_idx: int, dataloader_idx: int = 0) -> None:
+        super().on_test_batch_start(batch, batch_idx, dataloader_idx)
+        self._proposals = None
+
+    def _draws(self, B, K, D):
+        src = self.draw_source
+        if src is None:
+            return None
+        hp = self.hparams
+        I, Zd = hp.num_imp_samples, self.model.latent_dim
+        bern = self.model.hparams.generator_distribution.name == "bern"
+        uni = bool(self.model.hparams.use_uniform_prior)   # Uniform.sample draws torch.rand
+        d = {"eps_z": (src.uniform if uni else src.normal)(I, B, K, Zd)}
+        if hp.resampling_method == 'multinomial':
+            if hp.resampling_scheme in ('lr', 'ir'):
+                d["u_res"] = src.exponential(B * K, I)
+            else:
+                G = K // hp.glr_cluster_size if hp.resampling_scheme == 'glr' else 1
+                d["u_res"] = src.uniform64(B * G, K // G)
+        elif hp.resampling_scheme == 'gr':
+            d["u_res"] = src.uniform(B, 1)
+        elif hp.resampling_scheme == 'glr':
+            d["u_res"] = src.uniform(B, K // hp.glr_cluster_size, 1)
+        else:
+            d["u_res"] = src.uniform(B, K, 1)
+        d["eps_x"] = src.uniform(B, K, D) if bern else src.normal(B, K, D)
+        return d
+
+    def sampler(self, X, M):
+        hp = self.hparams
+        B, K, D = X.shape
+        X = X.clone().contiguous()
+        T = hp.num_iterations
+        for t in range(T):
+            ret = standard_importance_resampling(
+                self.model, X, M, hp.num_imp_samples, glr_cluster_size=hp.glr_cluster_size,
+                weighting=hp.weighting_scheme, resampling_method=hp.resampling_method,
+                resampling_scheme=hp.resampling_scheme, rng=self._rng(), draws=self._draws(B, K, D), inplace=True)
+            self._next_iteration()
+            X, ess, transformed_ess, perplexity, total_num_props, _, Z_prop, log_weights = ret
+            if self._proposals is None:
+                self._proposals = (torch.empty((T,) + tuple(Z_prop.shape), device=X.device),
+                                   torch.empty((T,) + tuple(log_weights.shape), device=X.device))
+            self._proposals[0][t].copy_(Z_prop)
+            self._proposals[1][t].copy_(log_weights)
+            yield {'X': X, 'is_ess_standard': ess.mean(), 'is_ess_not_reduced': ess,
+                   'perplexity_standard': perplexity.mean()}
+
+    def final_resampling(self, X_true, M):
+        return _final_resampling(self, self._proposals, X_true, M, self.hparams.resample_final_imps_num_samples)
+
+    def on_test_batch_end(self, outputs, batch: Any, batch_idx: int, dataloader_idx: int = 0) -> None:
+        super().on_test_batch_end(outputs, batch, batch_idx, dataloader_idx)
+        X_true, M = batch[:2]
+        I = batch[-1]
+        M1 = M.to(self.device).bool().unsqueeze(1)
+        imps, _, _ = self.final_resampling(X_true, M1)
+        imps = imps.cpu().numpy()
+        self.last_final_imputations = imps
+        if self.out_dir is not None:
+            os.makedirs(self.out_dir, exist_ok=True)
+            np.savez_compressed(os.path.join(self.out_dir, f'imputations_{batch_idx}.npz'), imputations=imps,
+                                true_X=X_true.unsqueeze(1).cpu().numpy(), masks=M1.cpu().numpy(),
+                                data_idx=np.asarray(I.cpu() if torch.is_tensor(I) else I))
 
 
 class TestVAEPseudoGibbs(TestVAESamplerBase):

@@ -2,8 +2,8 @@
 HIP library.
 
 Counterparts of ``irwg/sampling/vae_imputation.py``:
-``importance_resampling_gibbs_iteration`` (:484-726), ``pseudo_gibbs_iteration`` (:19-45),
-``expand_M_dim`` (:14-17).  Two keyword-only extensions exist on every stochastic function:
+``importance_resampling_gibbs_iteration`` (:484-726), ``standard_importance_resampling``
+(:904-998), ``pseudo_gibbs_iteration`` (:19-45), ``expand_M_dim`` (:14-17).  Two keyword-only extensions exist on every stochastic function:
 ``rng`` (a ``_lib.cs_rng`` counter-RNG key) and ``draws`` (dict of injected draws, used by
 the parity tests to feed this engine and the reference the same numbers).
 """
@@ -54,7 +54,7 @@ def importance_resampling_gibbs_iteration(model, X, M, num_imp_samples, *, glr_c
         raise NotImplementedError("historical proposals are not implemented")
     if weighting not in ("dmis", "dmis_within_groups", "smis"):
         raise NotImplementedError()
-    if resampling_scheme not in ("gr", "glr"):
+    if resampling_scheme not in ("gr", "glr", "lr", "ir"):
         raise NotImplementedError()
     if resampling_method not in ("multinomial", "systematic"):
         raise NotImplementedError()
@@ -78,6 +78,38 @@ def importance_resampling_gibbs_iteration(model, X, M, num_imp_samples, *, glr_c
     if return_resampled_latents:
         out = out + (ws.latents_resampled,)
     return out
+
+
+def standard_importance_resampling(model, X, M, num_imp_samples, *, glr_cluster_size=None,
+                                   weighting='dmis', resampling_method='multinomial', resampling_scheme='gr',
+                                   return_weights=False, weight_transform=None, data_channel_dim=None,
+                                   rng=None, draws=None, inplace=False):
+    """Importance resampling with the prior as the proposal of every chain (vae_imputation.py:904-998).
+    Returns the reference's 8-tuple ``X_new, ess, transformed_ess, perplexity, total_num_props,
+    norm_log_weights, Z_imp[I,B,K,Zd], log_weights[I,B,K]`` (views of the model's workspace).
+    With the uniform prior the injected 'eps_z' holds the samples of Uniform(0, 1 + 1e-8)."""
+    if data_channel_dim is not None:
+        raise NotImplementedError("data_channel_dim is not implemented")
+    if weighting not in ("dmis", "smis"):
+        raise NotImplementedError()
+    if resampling_scheme not in ("gr", "glr", "lr", "ir"):
+        raise NotImplementedError()
+    if resampling_method not in ("multinomial", "systematic"):
+        raise NotImplementedError()
+    if weight_transform is not None and not isinstance(weight_transform, (int, float)):
+        raise NotImplementedError("weight_transform must be None or a scalar multiplier")
+    if resampling_scheme == "glr":
+        assert glr_cluster_size is not None and glr_cluster_size > 1
+    B, K, D = X.shape
+    ws = engine.lair_workspace(model, B, K, 0, int(num_imp_samples), X.device)
+    cfg = engine.lair_cfg(model, ws, weighting=weighting, scheme=resampling_scheme, method=resampling_method,
+                          cluster_size=glr_cluster_size, weight_alpha=weight_transform)
+    if (cfg.prior == _lib.CS_PRIOR["uniform"]) != (cfg.latent_dist == _lib.CS_DIST["beta"]):
+        # the uniform prior is proposed as Beta(1, 1), which needs the Beta posterior's kernels
+        raise NotImplementedError("prior proposals: uniform prior with a non-Beta posterior (or the reverse)")
+    X_new = (X if inplace else X.clone()).contiguous()
+    engine.lair_step(model, ws, X_new, engine.mask_u8(M), cfg, rng=rng, draws=draws, prior_proposals=True)
+    return (X_new, ws.stats[0], ws.stats[1], ws.stats[2], ws.I * ws.Kp, ws.norm_log_w, ws.Z, ws.log_w)
 
 
 def pseudo_gibbs_iteration(model, X, M, clip_values_min=None, clip_values_max=None, *, data_channel_dim=None,

@@ -138,6 +138,13 @@ typedef struct {
   int32_t prior;        /* CS_PRIOR_* */
   float proposal_temperature; /* var_proposal_temperature (0 = off): see cs_proposal_transform */
   int32_t proposal_anneal;    /* CS_ANNEAL_* (var_proposal_anneal_type_to_prior) */
+  /* Historical proposals (vae_imputation.py:504-548, 677-680): X then holds K chains of which only
+   * the first K_impute are imputed (the others are imputations taken from the history, appended by
+   * cs_history_concat, that only propose); 0 = all K.  glr_pad_to > 0: global-local resampling and
+   * the grouped weights lay their groups out for glr_pad_to proposals of which only K' exist
+   * (the iterations before the history is used, :546-548). */
+  int32_t K_impute;
+  int32_t glr_pad_to;
 } cs_lair_cfg;
 
 typedef struct {
@@ -157,19 +164,32 @@ typedef struct {
   float* gen_ll;       /* [I,B,K'] masked log-likelihood of X under each proposal */
   float* log_w;        /* [I,B,K'] */
   float* norm_log_w;   /* [B,I*K'] (gr '(i k)'; glr '(g i c)'; lr '(k i)'; ir: the log-weights, '(i k)') */
-  int64_t* idx;        /* [B,K'] source proposal (flattened i*K'+k') of output slot */
+  int64_t* idx;        /* [B,NS] source proposal (flattened i*K'+k') of output slot; NS = K', or
+                          glr_pad_to when the padded group layout is in use */
   float* ess;          /* [B] */
   float* tess;         /* [B] ESS of the transformed weights */
   float* perplexity;   /* [B] */
-  float* latents_resampled; /* optional [B,K',Zd] (return_resampled_latents) */
-  int64_t* idx2;            /* optional [B,K'] indices of that second resampling */
+  float* latents_resampled; /* optional [B,NS,Zd] (return_resampled_latents) */
+  int64_t* idx2;            /* optional [B,NS] indices of that second resampling */
   const float* clip_min;    /* optional [D] (test_step_vae_sampling.py:1942-1950) */
   const float* clip_max;
   /* lr / ir with the multinomial method draw ONE index per chain: torch.multinomial(p, 1) is
    * argmax(p / e) with e ~ Exp(1) per candidate; injected e[B,K',I] (NULL -> counter RNG) */
   const float* e_res;
   const float* e_res2;
+  float* X_out; /* optional [B,K_impute,D]: the new imputations go here instead of in place */
 } cs_lair_bufs;
+
+/* Historical proposals of LAIR (ImputationHistoryQueue.sample_history /
+ * sample_history_with_chain_idx_for_each_sample, irwg/sampling/utils.py:28-68, and the concat of
+ * vae_imputation.py:543-545): Xc[b, :K] = X[b], Xc[b, K+h] = ring[slots[h], b, chain], where the
+ * ring is [hist_len,B,K,D] in device memory and slots[H] (HOST array, the stratified window draws
+ * shifted by the tail, computed by the caller) is common to the batch.  The chain is
+ * chain_of_proposal[h] (HOST array; global-local resampling) or, when that is NULL,
+ * chain_of_example[b] (device, int64) or, when that is NULL too, a counter-RNG draw per example. */
+int cs_history_concat(const float* X, const float* ring, int64_t B, int32_t K, int32_t D, int32_t H,
+                      const int32_t* slots, const int32_t* chain_of_proposal, const int64_t* chain_of_example,
+                      const cs_rng* rng, float* Xc, void* stream);
 
 /* Tempering and annealing of proposal parameters, in place on q[B,K',2,Zd] rows k < K:
  * VAE.distribution_param_tempering (vae.py:258-306: scale * temperature; Beta: concentrations *
@@ -276,7 +296,8 @@ int cs_acmwg_init_state(const cs_mlp_t* enc, const cs_mlp_t* dec, const cs_acmwg
 int cs_acmwg_step(const cs_mlp_t* enc, const cs_mlp_t* dec, const cs_acmwg_cfg* cfg, const cs_acmwg_bufs* b,
                   const cs_rng* rng, void* stream);
 /* enqueue_batch (utils.py:101-113): ages the counters when the ring was already full, then
- * writes X[B,K,D] into slot new_tail. */
+ * writes X[B,K,D] into slot new_tail.  With was_full = 0 (avail may then be NULL) it is the
+ * enqueue of the plain ImputationHistoryQueue of LAIR (utils.py:14-16). */
 int cs_history_enqueue(float* ring, int64_t* avail, int32_t hist_len, int32_t new_tail, int32_t was_full,
                        const float* X, int64_t B, int32_t K, int32_t D, void* stream);
 /* update_available_timesteps (utils.py:94-99): avail[mask] = len (mask NULL: all chains). */

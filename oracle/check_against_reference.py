@@ -301,7 +301,8 @@ def check_single_sample_multinomial():
     print("[ok] single-sample multinomial = argmax(p / Exp(1))")
 
 
-def case_lair_sampler(ns, name, *, B, K, R, D, Zd, H, seed, T, n_final=None, freq=1):
+def case_lair_sampler(ns, name, *, B, K, R, D, Zd, H, seed, T, n_final=None, freq=1, final=True, scheme="gr",
+                      weighting="dmis", cluster=None, pg_warmup=0, num_hist=None, no_hist_its=None, hist_len=None):
     import tempfile, types
     from oracle import cs_oracle_samplers as S
     enc = O.make_resfc_weights(D, 2 * Zd, 1, H, seed)
@@ -311,10 +312,12 @@ def case_lair_sampler(ns, name, *, B, K, R, D, Zd, H, seed, T, n_final=None, fre
     g = torch.Generator().manual_seed(seed + 5)
     X_true = X[:, 0].clone()
     tester = ns.test_step.TestVAELatentAdaptiveImportanceResampling(
-        num_iterations=T, num_imp_samples=1, weighting_scheme="dmis", resampling_scheme="gr",
-        resampling_method="multinomial", num_prior_replenish_proposals=R,
-        prior_replenish_iteration_frequency=freq, resample_final_imps=True,
-        resample_final_imps_num_samples=n_final, store_latents=True, num_copies=K, **BASE_KW)
+        num_iterations=T, num_imp_samples=1, weighting_scheme=weighting, resampling_scheme=scheme,
+        resampling_method="multinomial", num_prior_replenish_proposals=R, glr_cluster_size=cluster,
+        prior_replenish_iteration_frequency=freq, resample_final_imps=final,
+        resample_final_imps_num_samples=n_final, store_latents=True, num_copies=K,
+        num_pseudo_warmup_iterations=pg_warmup, num_historical_proposals=num_hist,
+        no_historic_proposals_iterations=no_hist_its, imputation_history_length=hist_len, **BASE_KW)
     tester.set_model(vae)
     tmp = tempfile.mkdtemp()
     tester.logger = types.SimpleNamespace(experiment=types.SimpleNamespace(get_logdir=lambda: tmp))
@@ -326,15 +329,24 @@ def case_lair_sampler(ns, name, *, B, K, R, D, Zd, H, seed, T, n_final=None, fre
         for o in tester.sampler(X.clone(), M):
             ref_out.append({k: (v.clone() if torch.is_tensor(v) else v) for k, v in o.items()})
         tester.on_test_batch_end(None, batch, 0, 0)
-    final = dict(np.load(os.path.join(tmp, "irwg_imputations_after_final_resampling_0.npz")))
-    entries = tape.entries
+    final_res = final
+    final = dict(np.load(os.path.join(tmp, "irwg_imputations_after_final_resampling_0.npz"))) if final_res else {}
+    entries = S.compact_tape(tape.entries)
     src = S.TapeSource(entries)
     ora = list(S.lair_sampler(enc, dec, X.clone(), M, src, num_iterations=T, num_prior_replenish_proposals=R,
-                              prior_replenish_iteration_frequency=freq, store_latents=True, collect_proposals=True))
+                              prior_replenish_iteration_frequency=freq, store_latents=True, collect_proposals=True,
+                              resampling_scheme=scheme, weighting_scheme=weighting, glr_cluster_size=cluster,
+                              num_pseudo_warmup_iterations=pg_warmup, num_historical_proposals=num_hist,
+                              no_historic_proposals_iterations=no_hist_its, imputation_history_length=hist_len))
+    assert len(ora) == len(ref_out) == T + pg_warmup
     for t, (a, r) in enumerate(zip(ora, ref_out)):
         assert torch.equal(a["X"], r["X"]), f"X[{t}]"
-        close(a["Z"], r["Z"], "Z"); close(a["is_ess"], torch.as_tensor(r["is_ess"]), "ess")
-    if freq == 1:
+        close(a["Z"], r["Z"], "Z"); close(torch.as_tensor(a["is_ess"]), torch.as_tensor(r["is_ess"]), "ess")
+    if not final_res:
+        assert src.pos == len(entries), "oracle did not consume the whole tape"
+        idx = torch.zeros(0)
+        final = dict(imputations=np.zeros(0, np.float32), latents=np.zeros(0, np.float32))
+    elif freq == 1:
         idx, Zf, imps = S.lair_final_resample(dec, [a["Z_prop"] for a in ora], [a["log_weights"] for a in ora],
                                               X_true, M, src, num_samples=n_final)
         assert src.pos == len(entries)
@@ -344,11 +356,17 @@ def case_lair_sampler(ns, name, *, B, K, R, D, Zd, H, seed, T, n_final=None, fre
     fx.update(S.tape_to_npz_dict(entries))
     fx.update(X0=X.numpy(), M=M.numpy(), X_true=X_true.numpy(),
               cfg=np.array([B, K, R, D, Zd, H, T, n_final or 0, freq], dtype=np.int64),
+              hist_cfg=np.array([pg_warmup, -1 if num_hist is None else num_hist, -1 if no_hist_its is None else no_hist_its,
+                                 hist_len or 0, cluster or 0, int(final_res)], dtype=np.int64),
+              scheme=np.array(scheme), weighting=np.array(weighting),
               X_seq=np.stack([r["X"].numpy() for r in ref_out]),
-              Z_seq=np.stack([r["Z"].numpy() for r in ref_out]),
               is_ess=np.array([float(r["is_ess"]) for r in ref_out], dtype=np.float32),
               final_imputations=final["imputations"], final_latents=final["latents"],
               final_idx=idx.numpy())
+    if len({tuple(r["Z"].shape) for r in ref_out}) == 1:
+        fx["Z_seq"] = np.stack([r["Z"].numpy() for r in ref_out])
+    else:   # the proposal count changes when the history joins: one array per iteration
+        fx.update({f"Z_t{t}": r["Z"].numpy() for t, r in enumerate(ref_out)})
     np.savez_compressed(os.path.join(GOLDEN, f"{name}.npz"), **fx)
     print(f"[ok] {name}")
 
@@ -431,6 +449,11 @@ def main():
     case_pseudo_gibbs(ns, "pseudo_gibbs_noclip", B=3, K=2, D=6, Zd=3, H=64, seed=979, T=5, clip=False)
     case_lair_sampler(ns, "lair_sampler_final", B=4, K=3, R=1, D=8, Zd=4, H=64, seed=111, T=5)
     case_lair_sampler(ns, "lair_sampler_final_n5", B=3, K=4, R=1, D=8, Zd=4, H=64, seed=222, T=4, n_final=5)
+    case_lair_sampler(ns, "lair_sampler_history_gr", B=4, K=3, R=1, D=8, Zd=4, H=64, seed=333, T=7, final=False,
+                      pg_warmup=2, num_hist=2, no_hist_its=3, hist_len=4)
+    case_lair_sampler(ns, "lair_sampler_history_glr", B=3, K=5, R=0, D=8, Zd=4, H=64, seed=444, T=12, final=False,
+                      scheme="glr", weighting="dmis_within_groups", cluster=5, pg_warmup=2, num_hist=10,
+                      no_hist_its=10, hist_len=12)
 
 
 if __name__ == "__main__":

@@ -311,9 +311,14 @@ def dmis_mixture_logprob(Z, q_loc, q_scale, latent_dist="normal"):
     return lp.transpose(0, -1).squeeze(0)  # [I,B,K]
 
 
-def grouped_dmis_mixture_logprob(Z, q_loc, q_scale, cluster_size, latent_dist="normal"):
-    """Mixture restricted to the proposal's own group (vae_imputation.py:407-434, no
-    padding).  Layout '(c k)': member j belongs to group j mod (K/c); a group has c members."""
+def grouped_dmis_mixture_logprob(Z, q_loc, q_scale, cluster_size, latent_dist="normal", pad_to=None):
+    """Mixture restricted to the proposal's own group (vae_imputation.py:407-434).  Layout
+    '(c k)': member j belongs to group j mod (K/c); a group has c members.  With ``pad_to`` the
+    K proposals are laid out as if there were pad_to of them (group j mod (pad_to/c)); the
+    missing members contribute nothing and the mixture is normalised by the number of members
+    actually present (:395-405, 423-427)."""
+    if pad_to is not None:
+        return _grouped_dmis_padded(Z, q_loc, q_scale, cluster_size, latent_dist, pad_to)
     I, B, K, Zd = Z.shape
     c = cluster_size
     G = K // c
@@ -328,15 +333,32 @@ def grouped_dmis_mixture_logprob(Z, q_loc, q_scale, cluster_size, latent_dist="n
     return lp.permute(0, 1, 3, 2).reshape(I, B, K)                # i b (c g)
 
 
+def _grouped_dmis_padded(Z, q_loc, q_scale, c, latent_dist, pad_to):
+    I, B, K, Zd = Z.shape
+    G = pad_to // c
+    out = torch.empty(I, B, K)
+    for g in range(G):
+        members = [j for j in range(g, pad_to, G) if j < K]
+        if not members:
+            continue
+        mi = torch.tensor(members)
+        Zg = Z[:, :, mi]                                              # i b m d
+        lp = latent_log_prob(Zg.unsqueeze(3), q_loc[:, mi].unsqueeze(1), q_scale[:, mi].unsqueeze(1),
+                             latent_dist).sum(-1)                     # i b m(value) m(component)
+        lp = torch.logsumexp(lp, dim=-1) - torch.log(torch.tensor(len(members)))
+        out[:, :, mi] = lp
+    return out
+
+
 def lair_log_weights(X, M, Z, q_loc, q_scale, gen_params, gen_dist, weighting, cluster_size=None,
-                     latent_dist="normal", prior="std_normal"):
+                     latent_dist="normal", prior="std_normal", pad_to=None):
     """log w = sum_d M log p(x_d|z) + sum log p(z) - log q_mix(z)  (weights.py:46-57)."""
     gl = (gen_log_prob(X, gen_params, gen_dist) * M).sum(-1)
     pl = (uniform_prior_log_prob(Z) if prior == "uniform" else std_normal_log_prob(Z)).sum(-1)
     if weighting == "dmis":
         ql = dmis_mixture_logprob(Z, q_loc, q_scale, latent_dist)
     elif weighting == "dmis_within_groups":
-        ql = grouped_dmis_mixture_logprob(Z, q_loc, q_scale, cluster_size, latent_dist)
+        ql = grouped_dmis_mixture_logprob(Z, q_loc, q_scale, cluster_size, latent_dist, pad_to)
     elif weighting == "smis":
         ql = latent_log_prob(Z, q_loc, q_scale, latent_dist).sum(-1)
     else:
@@ -369,14 +391,22 @@ def gather_gr(params, idx):
     return flat[torch.arange(B)[:, None], idx]
 
 
-def glr_resample(log_w, u, cluster_size, method="multinomial"):
-    """Global-local resampling (vae_imputation.py:335-378, no padding).  Group g holds the
+def glr_resample(log_w, u, cluster_size, method="multinomial", pad_to=None):
+    """Global-local resampling (vae_imputation.py:335-378).  With ``pad_to`` the K' proposals are
+    padded with weight-zero members up to pad_to, which changes the group layout (G = pad_to/c);
+    the returned slot order and normalised log-weights follow the reference's (:339-341,371-374).  Group g holds the
     members j with j mod G == g (G = K'/c); it draws c indices among its I*c members laid
     out '(i c)'.  Returns local idx[B,G,c] (draw t of group g), the flattened global
     '(i k)' index of every output slot in the reference's output order '(c k)'
     (slot t*G+g), and norm_log_weights[B, G*I*c]."""
     I, B, K = log_w.shape
     c = cluster_size
+    if pad_to is not None:
+        Kreal = K
+        log_w = torch.cat([log_w, torch.ones(I, B, pad_to - K) * float("-inf")], dim=-1)
+        K = pad_to
+    else:
+        Kreal = None
     G = K // c
     lw = log_w.reshape(I, B, c, G).permute(1, 3, 0, 2).reshape(B, G, I * c)  # b g (i c)
     if method == "multinomial":
@@ -390,9 +420,14 @@ def glr_resample(log_w, u, cluster_size, method="multinomial"):
     i_loc = idx // c
     c_loc = idx % c
     g_ar = torch.arange(G)[None, :, None]
-    glob = i_loc * K + c_loc * G + g_ar                       # [B,G,c] flattened (i k)
+    kk = c_loc * G + g_ar                                     # proposal index inside importance sample i
+    glob = i_loc * (Kreal or K) + kk                          # [B,G,c] flattened (i k) over the real proposals
     glob_out = glob.permute(0, 2, 1).reshape(B, c * G)        # slot t*G+g
     nlw = lw - lw.logsumexp(dim=-1, keepdim=True)
+    if Kreal is not None:
+        assert bool((kk < Kreal).all()), "a padded member was drawn"
+        nlw = nlw.reshape(B, G, I, c).permute(2, 0, 3, 1).reshape(I, B, K)[:, :, :Kreal]   # i b (c k), real members
+        return idx, glob_out, nlw.permute(1, 0, 2).reshape(B, I * Kreal)
     return idx, glob_out, nlw.reshape(B, G * I * c)
 
 
@@ -448,8 +483,11 @@ def lair_iteration(enc, dec, X, M, draws, *, num_imp_samples=1, weighting="dmis"
                    return_resampled_latents=False, weight_alpha=None,
                    encoder=None, decoder=None, prior="std_normal",
                    var_proposal_temperature=None, var_proposal_anneal_type_to_prior=None,
-                   prior_proposals=False):
-    """One LAIR step (vae_imputation.py:484-726) with injected draws.  ``prior_proposals``:
+                   prior_proposals=False, hist_X=None, glr_pad_to=None):
+    """One LAIR step (vae_imputation.py:484-726) with injected draws.  ``hist_X`` [B,H,D]:
+    historical imputations appended as extra proposals (:504-545); they take part in the weights
+    and the resampling, only the first K chains are imputed (:677-680).  ``glr_pad_to``: the
+    iterations before the history is used lay their groups out as if it were (:546-548).  ``prior_proposals``:
     standard_importance_resampling instead (:904-998) -- no encoder, every chain proposes from the
     prior (N(0,1); the uniform prior as Uniform(0, 1+1e-8), 'eps_z' then holds torch.rand draws).  For latent_dist='beta'
     'eps_z' holds the Beta samples themselves (torch draws them by rejection sampling).
@@ -461,6 +499,9 @@ def lair_iteration(enc, dec, X, M, draws, *, num_imp_samples=1, weighting="dmis"
     forward (used for the conv nets)."""
     encoder = encoder or (lambda x: resfc_forward(enc, x))
     decoder = decoder or (lambda z: resfc_forward(dec, z))
+    B, K_keep, D = X.shape
+    if hist_X is not None:
+        X = torch.cat([X, hist_X], dim=1)                     # :545
     B, K, D = X.shape
     R = num_prior_replenish_proposals
     I = num_imp_samples
@@ -507,15 +548,15 @@ def lair_iteration(enc, dec, X, M, draws, *, num_imp_samples=1, weighting="dmis"
         Z = q_loc + q_scale * draws["eps_z"]                  # [I,B,K',Zd]
     gen_params = decoder(Z)                                   # [I,B,K',P]
     log_w, gl, pl, ql = lair_log_weights(Xp, Mf, Z, q_loc, q_scale, gen_params, gen_dist,
-                                         weighting, glr_cluster_size, latent_dist, prior)
-    return _lair_finish(out, X, Mf, Z, gen_params, log_w, gl, pl, ql, q_loc, q_scale, var_params, draws, I, K, Kp,
-                        resampling_scheme, resampling_method, glr_cluster_size, gen_dist, weight_alpha,
-                        return_resampled_latents)
+                                         weighting, glr_cluster_size, latent_dist, prior, glr_pad_to)
+    return _lair_finish(out, X[:, :K_keep], Mf, Z, gen_params, log_w, gl, pl, ql, q_loc, q_scale, var_params, draws, I,
+                        K_keep, Kp, resampling_scheme, resampling_method, glr_cluster_size, gen_dist, weight_alpha,
+                        return_resampled_latents, glr_pad_to)
 
 
 def _lair_finish(out, X, Mf, Z, gen_params, log_w, gl, pl, ql, q_loc, q_scale, var_params, draws, I, K, Kp,
                  resampling_scheme, resampling_method, glr_cluster_size, gen_dist, weight_alpha,
-                 return_resampled_latents):
+                 return_resampled_latents, glr_pad_to=None):
     """Resampling, sampling of the missing values, imputation and the ESS / perplexity statistics
     (vae_imputation.py:642-726), shared by the LAIR iteration and standard importance resampling."""
     B = X.shape[0]
@@ -526,7 +567,7 @@ def _lair_finish(out, X, Mf, Z, gen_params, log_w, gl, pl, ql, q_loc, q_scale, v
             idx, nlw = gr_resample(t_log_w, u, resampling_method)
             return idx, idx, nlw
         if resampling_scheme == "glr":
-            loc_idx, glob, nlw = glr_resample(t_log_w, u, glr_cluster_size, resampling_method)
+            loc_idx, glob, nlw = glr_resample(t_log_w, u, glr_cluster_size, resampling_method, glr_pad_to)
             return loc_idx, glob, nlw
         if resampling_scheme == "lr":
             return lr_resample(t_log_w, u, resampling_method)
@@ -658,6 +699,66 @@ def final_resample(latent_proposals, log_weights, u, num_samples):
     idx = multinomial_indices(categorical_probs(lw), u)
     Z = lp[torch.arange(B)[:, None], idx]
     return idx, Z
+
+
+# --------------------------------------------------------------------------------------
+# LAIR history of imputations (irwg/sampling/utils.py:5-68)
+# --------------------------------------------------------------------------------------
+class ImputationHistory:
+    """ImputationHistoryQueue with its integer draws injected.  Ring [T,B,K,D]; stratified
+    sampling: the stored history is cut into H windows, one index per window (the same for the
+    whole batch), shifted by the tail; then one chain per example (gr) or one chain per
+    historical proposal (glr)."""
+
+    def __init__(self, max_len, batch_shape, dtype=torch.float32):
+        self.T, self.tail, self.full = max_len, -1, False
+        self.queue = torch.zeros((max_len,) + tuple(batch_shape), dtype=dtype)
+
+    def __len__(self):
+        assert self.tail > -1
+        return self.T if self.full else self.tail + 1
+
+    def enqueue(self, X):
+        self.tail = (self.tail + 1) % self.T
+        if self.tail == self.T - 1:
+            self.full = True
+        self.queue[self.tail] = X
+
+    def window(self, H):
+        """Exclusive upper bound of the H window draws (utils.py:33-36)."""
+        return len(self) // H
+
+    def slots(self, r, H):
+        """Ring slots of the window draws r[H] (utils.py:37-39)."""
+        w = self.window(H)
+        return (torch.as_tensor(r) + torch.arange(0, H * w, w) + self.tail) % len(self)
+
+    def sample(self, r, chain_of_example, H):
+        """sample_history (utils.py:28-49) -> [H,B,D]."""
+        hp = self.queue[self.slots(r, H)]
+        B = self.queue.shape[1]
+        return hp[:, torch.arange(B), torch.as_tensor(chain_of_example)]
+
+    def sample_with_chain_idx(self, r, chain_of_proposal, H):
+        """sample_history_with_chain_idx_for_each_sample (utils.py:51-68) -> [H,B,D]."""
+        hp = self.queue[self.slots(r, H)]
+        return hp[torch.arange(H), :, torch.as_tensor(chain_of_proposal)]
+
+
+def glr_history_chain_idx(K, H, cluster_size):
+    """Chain of every historical proposal when global-local resampling is combined with the
+    history, so that each group only receives history of its own chains
+    (vae_imputation.py:505-537)."""
+    assert (K + H) % cluster_size == 0
+    G = (K + H) // cluster_size
+    assert G <= K
+    num_rem = math.ceil(K / G) * G - K
+    base = torch.cat([torch.arange(K), torch.arange(G - num_rem, G)])
+    reps = (K + H) // len(base)
+    chain = torch.cat(reps * [base])
+    if (K + H) % len(base) != 0:
+        chain = torch.cat([chain, base[:(K + H) - len(chain)]])
+    return chain[K:]
 
 
 # --------------------------------------------------------------------------------------

@@ -52,6 +52,17 @@ class TapeSource:
         """Exp(1) variates of a single-sample multinomial (argmax(p / e))."""
         return self._take(("exponential",), shape)
 
+    def randint_array(self, high, n):
+        """n integers in [0, high) drawn by ONE randint call of the reference (a size-1 call may
+        have been merged into a 'randint_block' by compact_tape)."""
+        kind, arr = self.entries[self.pos]
+        if kind == "randint" and arr.size == n and not (n == 1 and kind == "randint_block"):
+            out = self._take(("randint",), (n,)).to(torch.int64)
+        else:
+            out = torch.tensor([self.randint(high) for _ in range(n)], dtype=torch.int64)
+        assert bool(((out >= 0) & (out < high)).all())
+        return out
+
     def randint(self, high):
         """One integer in [0, high) per call, as the reference's history queue draws them.
         Consecutive single draws may be stored merged as one 'randint_block' entry."""
@@ -119,6 +130,9 @@ class SeededSource:
     def randint(self, high):
         return int(torch.randint(0, int(high), (1,), generator=self.g)[0])
 
+    def randint_array(self, high, n):
+        return torch.randint(0, int(high), (n,), generator=self.g)
+
 
 def initial_imputation(dec, X, M, src, gen_dist="normal_with_eps", prior="std_normal"):
     B, K, D = X.shape
@@ -128,22 +142,27 @@ def initial_imputation(dec, X, M, src, gen_dist="normal_with_eps", prior="std_no
     return O.vae_samples_imputation(dec, X, M, draws, gen_dist=gen_dist, prior=prior)
 
 
-def _lair_draws(src, I, B, K, R, D, Zd, *, scheme, method, cluster, gen_dist, second, latent_dist="normal"):
+def _lair_draws(src, I, B, K, R, D, Zd, *, scheme, method, cluster, gen_dist, second, latent_dist="normal",
+                K_out=None, pad_to=None):
+    """Draws of one LAIR iteration in the reference's order.  K counts every chain that proposes
+    (historical ones included), K_out the chains that are imputed, pad_to the padded proposal
+    count of glr before the history is used."""
     Kp = K + R
     d = {"eps_z": src.beta(I, B, Kp, Zd) if latent_dist == "beta" else src.normal(I, B, Kp, Zd)}
-    G = Kp // cluster if scheme == "glr" else 1
+    G = (pad_to or Kp) // cluster if scheme == "glr" else 1
+    K_out = K if K_out is None else K_out
 
     def res():
         if scheme in ("lr", "ir"):
             return src.exponential(B * Kp, I) if method == "multinomial" else src.uniform(B, Kp, 1)
         if method == "multinomial":
-            return src.uniform64(B * G, Kp // G)
+            return src.uniform64(B * G, (pad_to or Kp) // G)
         return src.uniform(B, 1) if scheme == "gr" else src.uniform(B, G, 1)
 
     d["u_res"] = res()
     if second:
         d["u_res2"] = res()
-    d["eps_x"] = src.uniform(B, K, D) if gen_dist == "bern" else src.normal(B, K, D)
+    d["eps_x"] = src.uniform(B, K_out, D) if gen_dist == "bern" else src.normal(B, K_out, D)
     return d
 
 
@@ -152,11 +171,24 @@ def lair_sampler(enc, dec, X, M, src, *, num_iterations, num_imp_samples=1, weig
                  num_prior_replenish_proposals=0, prior_replenish_iteration_frequency=1, store_latents=False,
                  clip_imputations=False, weight_transform=None, latent_dist="normal_with_eps",
                  gen_dist="normal_with_eps", collect_proposals=False, prior="std_normal",
-                 var_proposal_temperature=None, var_proposal_anneal_type_to_prior=None):
+                 var_proposal_temperature=None, var_proposal_anneal_type_to_prior=None,
+                 num_pseudo_warmup_iterations=0, num_historical_proposals=None,
+                 no_historic_proposals_iterations=None, imputation_history_length=None):
     """Generator over LAIR iterations; yields the dict the reference yields plus, when
-    ``collect_proposals``, 'Z_prop' and 'log_weights' for the final resampling."""
+    ``collect_proposals``, 'Z_prop' and 'log_weights' for the final resampling.  With
+    ``num_historical_proposals`` every imputation is stored in a history ring and, once
+    ``no_historic_proposals_iterations`` have passed, H stratified samples of it join the proposals
+    (:1866-1870, 1881-1882, 1894-1895, 1961-1962)."""
     B, K, D = X.shape
     Zd = O.net_input_dim(dec)
+    H = num_historical_proposals
+    history = O.ImputationHistory(imputation_history_length, X.shape, X.dtype) if H is not None else None
+    for t in range(num_pseudo_warmup_iterations):
+        draws = {"eps_z": src.normal(B, K, Zd), "eps_x": src.uniform(B, K, D) if gen_dist == "bern" else src.normal(B, K, D)}
+        X, Zpg = O.pseudo_gibbs_iteration(enc, dec, X, M, draws, latent_dist=latent_dist, gen_dist=gen_dist)
+        if history is not None:
+            history.enqueue(X)
+        yield {"X": X, "Z": Zpg, "is_ess": 0.0}
     if clip_imputations:
         Xt = X[:, 0].clone() * M.squeeze(1)
         clip_max = torch.max(Xt, dim=0)[0] * 2
@@ -166,10 +198,24 @@ def lair_sampler(enc, dec, X, M, src, *, num_iterations, num_imp_samples=1, weig
         alpha = None
         if weight_transform == "poly":
             alpha = min((t + 10) / num_iterations, 1)
-        draws = _lair_draws(src, num_imp_samples, B, K, R, D, Zd, scheme=resampling_scheme,
+        use_hist = (no_historic_proposals_iterations is not None
+                    and (num_pseudo_warmup_iterations + t) > no_historic_proposals_iterations)
+        hist_X, pad_to = None, None
+        if use_hist:
+            r = src.randint_array(history.window(H), H)
+            if resampling_scheme == "glr":
+                hist_X = history.sample_with_chain_idx(r, O.glr_history_chain_idx(K, H, glr_cluster_size), H)
+            else:
+                hist_X = history.sample(r, src.randint_array(K, B), H)
+            hist_X = hist_X.permute(1, 0, 2).to(X.dtype)
+        elif no_historic_proposals_iterations is not None and resampling_scheme == "glr" and H is not None:
+            pad_to = K + H                                    # vae_imputation.py:546-548
+        Kh = K + (H if use_hist else 0)
+        draws = _lair_draws(src, num_imp_samples, B, Kh, R, D, Zd, scheme=resampling_scheme,
                             method=resampling_method, cluster=glr_cluster_size, gen_dist=gen_dist,
-                            second=store_latents, latent_dist=latent_dist)
+                            second=store_latents, latent_dist=latent_dist, K_out=K, pad_to=pad_to)
         o = O.lair_iteration(enc, dec, X, M, draws, num_imp_samples=num_imp_samples, weighting=weighting_scheme, prior=prior,
+                             hist_X=hist_X, glr_pad_to=pad_to,
                              resampling_scheme=resampling_scheme, resampling_method=resampling_method,
                              glr_cluster_size=glr_cluster_size, num_prior_replenish_proposals=R,
                              latent_dist=latent_dist, gen_dist=gen_dist, return_resampled_latents=store_latents,
@@ -181,6 +227,8 @@ def lair_sampler(enc, dec, X, M, src, *, num_iterations, num_imp_samples=1, weig
             bad = ~X_m.isfinite()
             X_m = torch.where(bad, X, X_m)
         X = X_m
+        if history is not None:
+            history.enqueue(X)
         out = {"X": X, "Z": o["latents_resampled"], "is_ess": o["ess"].mean(), "is_ess_not_reduced": o["ess"],
                "transformed_ess": o["transformed_ess"].mean(), "perplexity": o["perplexity"].mean(),
                "total_num_props": o["total_num_props"], "acceptance_x": torch.tensor(1.)}

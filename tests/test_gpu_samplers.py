@@ -114,6 +114,34 @@ def test_lair_sampler_and_final_resampling_match_reference_golden(name):
     assert_close(imps, fx["final_imputations"], "final imputations")
 
 
+@pytest.mark.parametrize("name", ["lair_sampler_history_gr", "lair_sampler_history_glr"])
+def test_lair_sampler_with_historical_proposals_matches_reference_golden(name):
+    """LAIR with a pseudo-Gibbs warm-up, the imputation history and its stratified samples as extra
+    proposals; glr: padded group layout before the history is used, per-proposal chains after."""
+    from vae_conditional_sampling_amd.sampling.test_step_vae_sampling import \
+        TestVAELatentAdaptiveImportanceResampling as Sampler
+    fx = load_golden(name)
+    B, K, R, D, Zd, H, T, n_final, freq = [int(v) for v in fx["cfg"]]
+    pg, num_hist, no_hist, hist_len, cluster, final = [int(v) for v in fx["hist_cfg"]]
+    model = make_model(weights_from_fixture(fx, "enc"), weights_from_fixture(fx, "dec"))
+    s = Sampler(num_iterations=T, num_imp_samples=1, weighting_scheme=str(fx["weighting"]),
+                resampling_scheme=str(fx["scheme"]), resampling_method="multinomial", glr_cluster_size=cluster or None,
+                num_prior_replenish_proposals=R, store_latents=True, num_copies=K, num_pseudo_warmup_iterations=pg,
+                num_historical_proposals=num_hist, no_historic_proposals_iterations=no_hist,
+                imputation_history_length=hist_len, **BASE_KW)
+    s.set_model(model)
+    s.on_test_start()
+    s.draw_source = tape_source(fx)
+    s.on_test_batch_start(None, 0)
+    n = 0
+    for t, o in enumerate(s.sampler(torch.from_numpy(fx["X0"]).cuda(), torch.from_numpy(fx["M"]).cuda())):
+        assert_close(o["X"], fx["X_seq"][t], f"X[{t}]")
+        assert_close(o["Z"], fx[f"Z_t{t}"], f"Z[{t}]")
+        assert abs(float(o["is_ess"]) - float(fx["is_ess"][t])) <= 1e-4 * max(float(fx["is_ess"][t]), 1e-6)
+        n += 1
+    assert n == T + pg and s.draw_source.pos == len(s.draw_source.entries)
+
+
 @pytest.mark.parametrize("name", ["ir_sampler_gr", "ir_sampler_ir_smis", "ir_sampler_lr"])
 def test_importance_resampling_sampler_matches_reference_golden(name):
     """TestVAEImportanceResampling: prior proposals, gr / lr / ir resampling, final resampling."""

@@ -49,7 +49,7 @@ def test_unsupported_options_raise_not_implemented():
     s.on_test_start()
     X = torch.zeros(2, 2, 3); M = torch.ones(2, 1, 3, dtype=torch.bool)
     for bad in (dict(resampling_scheme="rr"), dict(weighting="nope"),
-                dict(resampling_method="residual"), dict(use_historical_proposals=True),
+                dict(resampling_method="residual"),
                 dict(var_proposal_anneal_type_to_prior="quadratic"), dict(accept_reject_xm=True)):
         with pytest.raises(NotImplementedError):
             importance_resampling_gibbs_iteration(None, X, M, 1, **bad)
@@ -147,3 +147,27 @@ def test_quadrant_and_nan_missingness():
     dm.setup("test")
     X, Mb, I = next(iter(dm.test_dataloader()))
     assert X.shape == (10, 196) and torch.equal(Mb, ~torch.isnan(X)) and Mb[:, :98].all() and not Mb[:, 98:].any()
+
+
+def test_history_queue_host_logic_and_glr_chain_index():
+    """Stratified slots of ImputationHistoryQueue (irwg/sampling/utils.py:33-39) and the chain index of
+    historical proposals under global-local resampling, whose known answer the reference documents
+    in its comments (vae_imputation.py:508-515): K=5, 10 historical samples, cluster size 5."""
+    from oracle import cs_oracle as O
+    from vae_conditional_sampling_amd.sampling.utils import ImputationHistoryQueue, glr_history_chain_idx
+    assert glr_history_chain_idx(5, 10, 5) == [2, 0, 1, 2, 3, 4, 2, 0, 1, 2]
+    for K, H, c in [(5, 10, 5), (4, 4, 4), (3, 3, 2), (6, 6, 4)]:
+        assert glr_history_chain_idx(K, H, c) == O.glr_history_chain_idx(K, H, c).tolist()
+    q = ImputationHistoryQueue(7, (2, 3, 4), device="cpu")
+    ref = O.ImputationHistory(7, (2, 3, 4))
+    for step in range(11):      # wraps after 7
+        q._increment_tail()
+        ref.enqueue(torch.zeros(2, 3, 4))
+        assert (q.tail_idx, q.full, len(q)) == (ref.tail, ref.full, len(ref))
+        for H in (1, 2, 3):
+            if len(q) < H:
+                continue
+            w = q.window_size(H)
+            assert w == ref.window(H)
+            r = [(step * 5 + h * 3) % w for h in range(H)]
+            assert q.slots_from_window_draws(r, H) == ref.slots(torch.tensor(r), H).tolist()

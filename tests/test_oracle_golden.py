@@ -123,3 +123,22 @@ def test_oracle_importance_resampling_sampler(name):
     assert src.pos == len(src.entries)
     assert np.array_equal(idx.numpy(), fx["final_idx"])
     assert_close(imps.unsqueeze(0), fx["final_imputations"], "final imputations")
+
+
+@pytest.mark.parametrize("name", ["lair_sampler_history_gr", "lair_sampler_history_glr"])
+def test_oracle_lair_sampler_with_history(name):
+    fx = load_golden(name)
+    B, K, R, D, Zd, H, T, n_final, freq = [int(v) for v in fx["cfg"]]
+    pg, num_hist, no_hist, hist_len, cluster, final = [int(v) for v in fx["hist_cfg"]]
+    enc, dec = weights_from_fixture(fx, "enc"), weights_from_fixture(fx, "dec")
+    src = S.TapeSource(S.tape_from_npz_dict(fx))
+    outs = list(S.lair_sampler(enc, dec, torch.from_numpy(fx["X0"]), torch.from_numpy(fx["M"]), src, num_iterations=T,
+                               num_prior_replenish_proposals=R, store_latents=True,
+                               resampling_scheme=str(fx["scheme"]), weighting_scheme=str(fx["weighting"]),
+                               glr_cluster_size=cluster or None, num_pseudo_warmup_iterations=pg,
+                               num_historical_proposals=num_hist, no_historic_proposals_iterations=no_hist,
+                               imputation_history_length=hist_len))
+    assert src.pos == len(src.entries) and len(outs) == T + pg
+    for t, o in enumerate(outs):
+        assert_close(o["X"], fx["X_seq"][t], f"X[{t}]")
+        assert_close(o["Z"], fx[f"Z_t{t}"], f"Z[{t}]")

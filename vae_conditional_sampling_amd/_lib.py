@@ -66,12 +66,13 @@ class cs_lair_cfg(C.Structure):
                 ("D", C.c_int32), ("Zd", C.c_int32), ("latent_dist", C.c_int32),
                 ("gen_dist", C.c_int32), ("weighting", C.c_int32), ("scheme", C.c_int32),
                 ("method", C.c_int32), ("cluster_size", C.c_int32), ("weight_alpha", C.c_float),
-                ("prior", C.c_int32), ("proposal_temperature", C.c_float), ("proposal_anneal", C.c_int32)]
+                ("prior", C.c_int32), ("proposal_temperature", C.c_float), ("proposal_anneal", C.c_int32),
+                ("K_impute", C.c_int32), ("glr_pad_to", C.c_int32)]
 
 
 _LAIR_BUF_FIELDS = ["X", "M", "eps_z", "u_res", "u_res2", "u_sys", "u_sys2", "eps_x", "q", "Z", "gen",
                     "gen_ll", "log_w", "norm_log_w", "idx", "ess", "tess", "perplexity",
-                    "latents_resampled", "idx2", "clip_min", "clip_max", "e_res", "e_res2"]
+                    "latents_resampled", "idx2", "clip_min", "clip_max", "e_res", "e_res2", "X_out"]
 
 
 class cs_lair_bufs(C.Structure):
@@ -131,6 +132,8 @@ def lib():
     L.cs_lair_step.argtypes = [vp, vp, C.POINTER(cs_lair_cfg), C.POINTER(cs_lair_bufs), C.POINTER(cs_rng), vp]
     L.cs_acmwg_init_state.argtypes = [vp, vp, C.POINTER(cs_acmwg_cfg), C.POINTER(cs_acmwg_bufs), C.POINTER(cs_rng), vp]
     L.cs_acmwg_step.argtypes = [vp, vp, C.POINTER(cs_acmwg_cfg), C.POINTER(cs_acmwg_bufs), C.POINTER(cs_rng), vp]
+    L.cs_history_concat.argtypes = [vp, vp, i64, i32, i32, i32, C.POINTER(i32), C.POINTER(i32), vp,
+                                    C.POINTER(cs_rng), vp, vp]
     L.cs_history_enqueue.argtypes = [vp, vp, i32, i32, i32, vp, i64, i32, i32, vp]
     L.cs_history_set_available.argtypes = [vp, vp, i64, i64, vp]
     L.cs_final_resample.argtypes = [vp, vp, i64, i64, i32, i32, vp, C.POINTER(cs_rng), i64, vp, vp, vp, vp]

@@ -321,9 +321,64 @@ extern "C" int cs_acmwg_step(const cs_mlp_t* enc, const cs_mlp_t* dec, const cs_
   return CS_OK;
 }
 
+// LAIR's historical proposals: Xc[b] = (X[b, 0..K), ring[slots[h], b, chain] for h < H).
+struct CsHistConcatArgs {
+  const float* X; const float* ring; float* Xc; const int64_t* chain_of_example; CsPhilox rng;
+  int64_t B; int K, D, H; int use_chain_of_proposal;
+  int slots[64]; int chain_of_proposal[64];
+};
+
+__global__ void __launch_bounds__(256) cs_history_concat_kernel(const CsHistConcatArgs a) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int KH = a.K + a.H;
+  if (t >= a.B * KH * a.D) return;
+  const int d = (int)(t % a.D);
+  const int64_t bk = t / a.D;
+  const int k = (int)(bk % KH);
+  const int64_t b = bk / KH;
+  float v;
+  if (k < a.K) {
+    v = a.X[(b * a.K + k) * a.D + d];
+  } else {
+    const int h = k - a.K;
+    int chain;
+    if (a.use_chain_of_proposal) {
+      chain = a.chain_of_proposal[h];
+    } else if (a.chain_of_example) {
+      chain = (int)a.chain_of_example[b];
+    } else {
+      uint32_t x[4];
+      cs_philox_block(a.rng, CS_STREAM_HIST, a.rng.row_offset + b, 0, x);
+      chain = (int)(((uint64_t)x[0] * (uint64_t)a.K) >> 32);
+    }
+    v = a.ring[(((int64_t)a.slots[h] * a.B + b) * a.K + chain) * a.D + d];
+  }
+  a.Xc[t] = v;
+}
+
+extern "C" int cs_history_concat(const float* X, const float* ring, int64_t B, int32_t K, int32_t D, int32_t H,
+                                 const int32_t* slots, const int32_t* chain_of_proposal, const int64_t* chain_of_example,
+                                 const cs_rng* rng, float* Xc, void* stream) {
+  CS_REQUIRE(X && ring && Xc && slots && B >= 0 && K >= 1 && D >= 1, "bad argument");
+  CS_REQUIRE(H >= 1 && H <= 64, "number of historical proposals must be in [1,64]");
+  if (B == 0) return CS_OK;
+  CsHistConcatArgs a;
+  a.X = X; a.ring = ring; a.Xc = Xc; a.chain_of_example = chain_of_example; a.rng = cs_make_philox(rng);
+  a.B = B; a.K = K; a.D = D; a.H = H; a.use_chain_of_proposal = chain_of_proposal != nullptr;
+  for (int h = 0; h < 64; ++h) {
+    a.slots[h] = h < H ? slots[h] : 0;
+    a.chain_of_proposal[h] = (h < H && chain_of_proposal) ? chain_of_proposal[h] : 0;
+    CS_REQUIRE(a.slots[h] >= 0 && a.chain_of_proposal[h] >= 0 && a.chain_of_proposal[h] < K, "bad slot / chain index");
+  }
+  const int64_t n = B * (K + H) * D;
+  hipLaunchKernelGGL(cs_history_concat_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+  CS_HIP(hipGetLastError());
+  return CS_OK;
+}
+
 extern "C" int cs_history_enqueue(float* ring, int64_t* avail, int32_t hist_len, int32_t new_tail, int32_t was_full,
                                   const float* X, int64_t B, int32_t K, int32_t D, void* stream) {
-  CS_REQUIRE(ring && avail && X && hist_len >= 1 && new_tail >= 0 && new_tail < hist_len, "bad argument");
+  CS_REQUIRE(ring && (avail || !was_full) && X && hist_len >= 1 && new_tail >= 0 && new_tail < hist_len, "bad argument");
   const int64_t chains = B * K, n = chains * D;
   if (n == 0) return CS_OK;
   hipLaunchKernelGGL(cs_history_enqueue_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,

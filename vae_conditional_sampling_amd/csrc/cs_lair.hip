@@ -20,8 +20,10 @@ struct CsResampleArgs {
   cs_lair_cfg cfg;
   cs_lair_bufs b;
   CsPhilox rng;
-  int Kp, S, G, c;       // resampling groups
+  int Kp, S, G, c;       // resampling groups: G groups, c draws each
   int mixG, mixc;        // mixture groups (dmis: 1,K'; within groups: G,c; smis: K',1)
+  int Kimp;              // chains that are imputed (<= K: historical proposals are not)
+  int NS;                // output slots of the resampling = G*c (K', or glr_pad_to when padded)
   int lds_per_wave;      // floats
   int E;                 // examples per wavefront
 };
@@ -52,14 +54,14 @@ __global__ void __launch_bounds__(64) cs_lair_resample_kernel(const CsResampleAr
   extern __shared__ float lds[];
   const int lane = threadIdx.x;
   const int B = a.cfg.B, K = a.cfg.K, D = a.cfg.D, Zd = a.cfg.Zd, I = a.cfg.I;
-  const int Kp = a.Kp, S = a.S, G = a.G, c = a.c, E = a.E;
+  const int Kp = a.Kp, S = a.S, G = a.G, c = a.c, E = a.E, NS = a.NS;
   const int64_t b0 = (int64_t)blockIdx.x * E;            // first example of this wave
   const int ne = (int)((B - b0) < E ? (B - b0) : E);     // examples present
   float* l_loc = lds;                      // [E][Kp*Zd]
   float* l_2var = l_loc + E * Kp * Zd;     // [E][Kp*Zd]  1/(2*scale^2)
   float* l_logs = l_2var + E * Kp * Zd;    // [E][Kp*Zd]  log(scale)
   float* l_z = l_logs + E * Kp * Zd;       // [E][S][Zd+1]
-  int* l_idx = (int*)(l_z + E * S * (Zd + 1));  // [E][2*Kp] resampled global indices (two draws)
+  int* l_idx = (int*)(l_z + E * S * (Zd + 1));  // [E][2*NS] resampled global indices (two draws)
 
   {
     const float* qb = a.b.q + b0 * Kp * 2 * Zd;
@@ -97,16 +99,24 @@ __global__ void __launch_bounds__(64) cs_lair_resample_kernel(const CsResampleAr
   // kp mod G, members in '(i c)' order (lr: G = K', c = 1, so the group of chain k holds its I
   // importance samples).  ir: the flattened '(i k)' axis is cut into K' runs of I consecutive
   // entries (the reference's reshape(B, K, -1), vae_imputation.py:463-464).
+  // With glr_pad_to the groups are laid out for a larger proposal count (G = pad_to / c) whose
+  // extra members do not exist: groups then hold fewer than I*c members (:339-341, 395-405).
   const bool ir = a.cfg.scheme == CS_RS_IR;
   const int g_s = ir ? s / I : kp_s % G;
-  const int cc_s = kp_s / G;
-  const int li_s = ir ? s - g_s * I : i_s * c + cc_s;
-  // bit jj: proposal jj of this example is in this lane's group (member order = lane order)
+  // bit jj: proposal jj of this example is in this lane's group; member order = lane order, and
+  // the lane index of a member is its flattened '(i k)' proposal index
   unsigned long long gmask = 0;
   for (int jj = 0; jj < S; ++jj) {
     const int gj = ir ? jj / I : (jj % Kp) % G;
     if (gj == g_s) gmask |= 1ull << jj;
   }
+  const int gsize = __popcll(gmask);
+  const int li_s = __popcll(gmask & ((1ull << s) - 1ull));  // position inside the group
+  auto nth_member = [&](int n) {                            // flattened index of the group's n-th member
+    unsigned long long m = gmask;
+    for (int q = 0; q < n; ++q) m &= m - 1ull;
+    return (int)__ffsll((long long)m) - 1;
+  };
 
   // reductions over the lanes of this example (optionally only its resampling group)
   auto seg_max = [&](float x, bool grouped) {
@@ -167,19 +177,22 @@ __global__ void __launch_bounds__(64) cs_lair_resample_kernel(const CsResampleAr
       ql = comp(kp_s);
     } else {
       float m = -INFINITY;
+      int ncomp = 0;
       for (int cc = 0; cc < a.mixc; ++cc) {
         const int j = gm + a.mixG * cc;
+        if (j >= Kp) break;  // padded layout: this member does not exist
         const float cj = comp(j);
         m = fmaxf(m, cj);
+        ++ncomp;
       }
       if (!(fabsf(m) < INFINITY)) m = 0.0f;
       float sum = 0.0f;
-      for (int cc = 0; cc < a.mixc; ++cc) {
+      for (int cc = 0; cc < ncomp; ++cc) {
         const int j = gm + a.mixG * cc;
         const float cj = comp(j);
         sum += expf(cj - m);
       }
-      ql = logf(sum) + m - logf((float)a.mixc);
+      ql = logf(sum) + m - logf((float)ncomp);
     }
     const int64_t rho = ((int64_t)i_s * B + b) * Kp + kp_s;
     lw = a.b.gen_ll[rho] + pl - ql;
@@ -207,7 +220,9 @@ __global__ void __launch_bounds__(64) cs_lair_resample_kernel(const CsResampleAr
   // ---- resampling within groups ----
   const float nl = tlw - seg_lse(tlw, true);  // normalised log-weight (Categorical.logits)
   // ir returns the (transformed) log-weights themselves, in '(i k)' order (vae_imputation.py:479-480)
-  if (act) a.b.norm_log_w[b * S + (ir ? s : g_s * (I * c) + li_s)] = ir ? tlw : nl;
+  // (padded glr returns them in '(i k)' order, :371-374)
+  const bool flat_nlw = ir || a.cfg.glr_pad_to > 0;
+  if (act) a.b.norm_log_w[b * S + (flat_nlw ? s : g_s * (I * c) + li_s)] = ir ? tlw : nl;
   float p;
   if (a.cfg.method == CS_RM_MULTINOMIAL) {
     // Categorical.probs = softmax(normalised logits)
@@ -226,13 +241,13 @@ __global__ void __launch_bounds__(64) cs_lair_resample_kernel(const CsResampleAr
     if ((gmask >> jj) & 1ull) run += pj;
     if (s == jj) cum = run;
   }
-  const bool last_in_group = li_s == I * c - 1;
+  const bool last_in_group = li_s == gsize - 1;
   // one draw per group (lr, ir): torch.multinomial(p, 1) = argmax(p / Exp(1)), first maximum
   const bool race = a.cfg.method == CS_RM_MULTINOMIAL && (a.cfg.scheme == CS_RS_LR || ir);
   const unsigned long long ex_mask = (S == 64 ? ~0ull : ((1ull << S) - 1ull)) << base;
 
   const int ndraw_sets = (a.b.latents_resampled != nullptr) ? 2 : 1;
-  int* my_idx = l_idx + e_l * 2 * Kp;
+  int* my_idx = l_idx + e_l * 2 * NS;
   for (int set = 0; set < ndraw_sets; ++set) {
     if (race) {
       const float* ein = set == 0 ? a.b.e_res : a.b.e_res2;
@@ -258,7 +273,7 @@ __global__ void __launch_bounds__(64) cs_lair_resample_kernel(const CsResampleAr
           ++cnt;
         }
       }
-      if (act && li_s == 0) my_idx[set * Kp + g_s] = ir ? g_s * I + best_li : best_li * Kp + g_s;
+      if (act && li_s == 0) my_idx[set * NS + g_s] = nth_member(best_li);
     } else if (a.cfg.method == CS_RM_MULTINOMIAL) {
       // torch.multinomial: cum / total, last forced to 1, left bisection with float64 uniforms
       float cn = cum / run;
@@ -274,9 +289,11 @@ __global__ void __launch_bounds__(64) cs_lair_resample_kernel(const CsResampleAr
           }
           const unsigned long long mask = __ballot(act && g_s == g && (double)cn < u);
           int li = __popcll(mask & ex_mask);
-          if (li > I * c - 1) li = I * c - 1;
-          const int il = li / c, cl = li - il * c;
-          if (act && s == 0) my_idx[set * Kp + t * G + g] = il * Kp + cl * G + g;
+          // the group's first member records the draw; output slot t*G + g ('c b k d -> b (c k) d')
+          if (act && g_s == g && li_s == 0) {
+            if (li > gsize - 1) li = gsize - 1;
+            my_idx[set * NS + t * G + g] = nth_member(li);
+          }
         }
       }
     } else {
@@ -294,50 +311,55 @@ __global__ void __launch_bounds__(64) cs_lair_resample_kernel(const CsResampleAr
         for (int t = 0; t < c; ++t) {
           const unsigned long long mask = __ballot(act && g_s == g && n <= t);
           int li = __popcll(mask & ex_mask);
-          if (li > I * c - 1) li = I * c - 1;  // the reference would index out of bounds here
-          const int il = li / c, cl = li - il * c;
-          if (act && s == 0) my_idx[set * Kp + t * G + g] = ir ? g * I + li : il * Kp + cl * G + g;
+          if (act && g_s == g && li_s == 0) {
+            if (li > gsize - 1) li = gsize - 1;  // the reference would index out of bounds here
+            my_idx[set * NS + t * G + g] = nth_member(li);
+          }
         }
       }
     }
   }
   __syncthreads();
-  for (int t = lane; t < ne * Kp; t += 64) {
-    const int e = t / Kp, n = t - e * Kp;
-    a.b.idx[(b0 + e) * Kp + n] = l_idx[e * 2 * Kp + n];
-    if (ndraw_sets == 2 && a.b.idx2) a.b.idx2[(b0 + e) * Kp + n] = l_idx[e * 2 * Kp + Kp + n];
+  for (int t = lane; t < ne * NS; t += 64) {
+    const int e = t / NS, n = t - e * NS;
+    a.b.idx[(b0 + e) * NS + n] = l_idx[e * 2 * NS + n];
+    if (ndraw_sets == 2 && a.b.idx2) a.b.idx2[(b0 + e) * NS + n] = l_idx[e * 2 * NS + NS + n];
   }
 
   // ---- resampled latents (second, independent draw; vae_imputation.py:649-650) ----
   if (ndraw_sets == 2) {
-    for (int t = lane; t < ne * Kp * Zd; t += 64) {
+    for (int t = lane; t < ne * NS * Zd; t += 64) {
       const int en = t / Zd, d = t - en * Zd;
-      const int e = en / Kp, n = en - e * Kp;
-      a.b.latents_resampled[b0 * Kp * Zd + t] = l_z[(e * S + l_idx[e * 2 * Kp + Kp + n]) * (Zd + 1) + d];
+      const int e = en / NS, n = en - e * NS;
+      a.b.latents_resampled[b0 * NS * Zd + t] = l_z[(e * S + l_idx[e * 2 * NS + NS + n]) * (Zd + 1) + d];
     }
   }
 
   // ---- sample the missing values from the resampled generator parameters and impute ----
   // work item = 4 consecutive dimensions of one chain (one Philox block = 4 normals)
+  // Only the first Kimp chains are imputed (the historical ones beyond them only propose); the new
+  // values go to X_out[B,Kimp,D] when given, else in place.
   const int DQ = (D + 3) >> 2;
   const bool bern = a.cfg.gen_dist == CS_DIST_BERN;
   const bool clip = a.b.clip_min || a.b.clip_max;
-  for (int t = lane; t < ne * K * DQ; t += 64) {
+  const int Kimp = a.Kimp;
+  for (int t = lane; t < ne * Kimp * DQ; t += 64) {
     const int en = t / DQ, dq = t - en * DQ;
-    const int e = en / K, n = en - e * K;
+    const int e = en / Kimp, n = en - e * Kimp;
     const int64_t be = b0 + e;
-    const int src = l_idx[e * 2 * Kp + n];
+    const int src = l_idx[e * 2 * NS + n];
     const int i = src / Kp, kp = src - i * Kp;
     const int64_t rho = ((int64_t)i * B + be) * Kp + kp;
-    float* xr = a.b.X + (be * K + n) * D;
+    const float* xr = a.b.X + (be * K + n) * D;
+    float* xw = a.b.X_out ? a.b.X_out + (be * Kimp + n) * D : a.b.X + (be * K + n) * D;
     const uint8_t* mr = a.b.M + be * D;
     float dr[4];
     if (a.b.eps_x) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) dr[r] = (4 * dq + r < D) ? a.b.eps_x[(be * K + n) * D + 4 * dq + r] : 0.0f;
+      for (int r = 0; r < 4; ++r) dr[r] = (4 * dq + r < D) ? a.b.eps_x[(be * Kimp + n) * D + 4 * dq + r] : 0.0f;
     } else {
       uint32_t x[4];
-      cs_philox_block(a.rng, CS_STREAM_X, (a.rng.row_offset + be) * K + n, (uint32_t)dq, x);
+      cs_philox_block(a.rng, CS_STREAM_X, (a.rng.row_offset + be) * Kimp + n, (uint32_t)dq, x);
       if (bern) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) dr[r] = cs_u01f(x[r]);
@@ -359,7 +381,7 @@ __global__ void __launch_bounds__(64) cs_lair_resample_kernel(const CsResampleAr
         if (a.b.clip_min) xn = (xn != xn) ? xn : fmaxf(xn, a.b.clip_min[d]);
         if (a.b.clip_max) xn = (xn != xn) ? xn : fminf(xn, a.b.clip_max[d]);
         if (clip && !(fabsf(xn) < INFINITY)) xn = xo;
-        xr[d] = xn;
+        xw[d] = xn;
       }
     }
   }
@@ -532,11 +554,16 @@ extern "C" int cs_lair_resample_impute(const cs_lair_cfg* c, const cs_lair_bufs*
   a.Kp = c->K + c->R;
   a.S = c->I * a.Kp;
   CS_REQUIRE(a.S <= 64, "I*(K+R) must be <= 64");
+  a.Kimp = c->K_impute > 0 ? c->K_impute : c->K;
+  CS_REQUIRE(a.Kimp <= c->K, "K_impute must be <= K");
+  CS_REQUIRE(c->glr_pad_to == 0 || c->glr_pad_to >= a.Kp, "glr_pad_to must be >= K+R");
+  // proposal count that the group layout of glr / dmis_within_groups is built for
+  const int Kg = c->glr_pad_to > 0 && c->scheme == CS_RS_GLR ? c->glr_pad_to : a.Kp;
   if (c->scheme == CS_RS_GR) {
     a.G = 1; a.c = a.Kp;
   } else if (c->scheme == CS_RS_GLR) {
-    CS_REQUIRE(c->cluster_size > 1 && a.Kp % c->cluster_size == 0, "glr needs cluster_size > 1 dividing K+R");
-    a.c = c->cluster_size; a.G = a.Kp / a.c;
+    CS_REQUIRE(c->cluster_size > 1 && Kg % c->cluster_size == 0, "glr needs cluster_size > 1 dividing K+R (or glr_pad_to)");
+    a.c = c->cluster_size; a.G = Kg / a.c;
   } else if (c->scheme == CS_RS_LR || c->scheme == CS_RS_IR) {
     a.c = 1; a.G = a.Kp;  // one draw per chain among I candidates
   } else {
@@ -545,8 +572,8 @@ extern "C" int cs_lair_resample_impute(const cs_lair_cfg* c, const cs_lair_bufs*
   if (c->weighting == CS_W_DMIS) {
     a.mixG = 1; a.mixc = a.Kp;
   } else if (c->weighting == CS_W_DMIS_WITHIN_GROUPS) {
-    CS_REQUIRE(c->cluster_size > 1 && a.Kp % c->cluster_size == 0, "grouped weights need cluster_size > 1 dividing K+R");
-    a.mixc = c->cluster_size; a.mixG = a.Kp / a.mixc;
+    CS_REQUIRE(c->cluster_size > 1 && Kg % c->cluster_size == 0, "grouped weights need cluster_size > 1 dividing K+R");
+    a.mixc = c->cluster_size; a.mixG = Kg / a.mixc;
   } else if (c->weighting == CS_W_SMIS) {
     a.mixG = a.Kp; a.mixc = 1;
   } else {
@@ -554,7 +581,8 @@ extern "C" int cs_lair_resample_impute(const cs_lair_cfg* c, const cs_lair_bufs*
   }
   CS_REQUIRE(c->method == CS_RM_MULTINOMIAL || c->method == CS_RM_SYSTEMATIC, "bad resampling method");
   if (c->B == 0) return CS_OK;
-  const int per_example = 3 * a.Kp * c->Zd + a.S * (c->Zd + 1) + 2 * a.Kp;  // floats of LDS
+  a.NS = a.G * a.c;
+  const int per_example = 3 * a.Kp * c->Zd + a.S * (c->Zd + 1) + 2 * a.NS;  // floats of LDS
   a.E = 64 / a.S;
   // more examples per wavefront fill more lanes, but the LDS working set limits how many
   // wavefronts are resident; ~12 KB per wavefront measured best (MiniBooNE shape)

@@ -20,9 +20,10 @@ def mask_u8(M):
 class LairWorkspace:
     """Device buffers of one LAIR configuration (B, K, R, I)."""
 
-    def __init__(self, model, B, K, R, I, device):
+    def __init__(self, model, B, K, R, I, device, slots=None):
         self.B, self.K, self.R, self.I = B, K, R, I
         self.Kp = K + R
+        self.NS = slots or self.Kp   # output slots of the resampling (glr with a padded layout: more than K')
         self.D = model.generator_network.output_dim // (1 if model.hparams.generator_distribution.name == "bern" else 2)
         self.Zd = model.latent_dim
         self.P = model.generator_network.output_dim
@@ -34,25 +35,25 @@ class LairWorkspace:
         self.gen_ll = torch.empty(I, B, Kp, **f)
         self.log_w = torch.empty(I, B, Kp, **f)
         self.norm_log_w = torch.empty(B, I * Kp, **f)
-        self.idx = torch.empty(B, Kp, device=device, dtype=torch.int64)
+        self.idx = torch.empty(B, self.NS, device=device, dtype=torch.int64)
         self.stats = torch.empty(3, B, **f)  # ess, transformed ess, perplexity
         self.latents_resampled = None
         self.idx2 = None
 
     def want_latents(self):
         if self.latents_resampled is None:
-            self.latents_resampled = torch.empty(self.B, self.Kp, self.Zd, device=self.q.device, dtype=torch.float32)
-            self.idx2 = torch.empty(self.B, self.Kp, device=self.q.device, dtype=torch.int64)
+            self.latents_resampled = torch.empty(self.B, self.NS, self.Zd, device=self.q.device, dtype=torch.float32)
+            self.idx2 = torch.empty(self.B, self.NS, device=self.q.device, dtype=torch.int64)
 
 
-def lair_workspace(model, B, K, R, I, device):
+def lair_workspace(model, B, K, R, I, device, slots=None):
     cache = model.__dict__.setdefault("_cs_workspaces", {})
-    key = ("lair", B, K, R, I, str(device))
+    key = ("lair", B, K, R, I, str(device)) if slots is None else ("lair", B, K, R, I, str(device), slots)
     ws = cache.get(key)
     if ws is None:
         if len(cache) > 8:
             cache.clear()
-        ws = cache[key] = LairWorkspace(model, B, K, R, I, device)
+        ws = cache[key] = LairWorkspace(model, B, K, R, I, device, slots)
     return ws
 
 
@@ -71,7 +72,7 @@ def lair_cfg(model, ws, *, weighting, scheme, method, cluster_size, weight_alpha
 
 
 def lair_step(model, ws, X, M8, cfg, *, rng=None, draws=None, return_resampled_latents=False,
-              clip_min=None, clip_max=None, prior_proposals=False):
+              clip_min=None, clip_max=None, prior_proposals=False, X_out=None):
     """One LAIR iteration in place on ``X`` [B,K,D] (cs_lair_step).  ``prior_proposals``: every
     chain proposes from the prior instead of the encoder (standard importance resampling)."""
     draws = draws or {}
@@ -96,7 +97,7 @@ def lair_step(model, ws, X, M8, cfg, *, rng=None, draws=None, return_resampled_l
                           perplexity=ws.stats[2],
                           latents_resampled=ws.latents_resampled if return_resampled_latents else None,
                           idx2=ws.idx2 if return_resampled_latents else None,
-                          clip_min=clip_min, clip_max=clip_max, **ud)
+                          clip_min=clip_min, clip_max=clip_max, X_out=X_out, **ud)
     rng = rng if rng is not None else _lib.make_rng(0)
     dec = model.generator_network.packed()
     L, st = _lib.lib(), _lib.current_stream()

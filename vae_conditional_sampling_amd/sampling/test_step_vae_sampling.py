@@ -27,7 +27,7 @@ import torch
 from .. import _lib
 from ..utils.hparams import HyperparametersMixin
 from . import engine, imputation_metrics
-from .utils import ImputationHistoryQueue_with_restrictedavailability
+from .utils import ImputationHistoryQueue, ImputationHistoryQueue_with_restrictedavailability
 from .vae_imputation import (importance_resampling_gibbs_iteration, pseudo_gibbs_iteration,
                              standard_importance_resampling)
 
@@ -391,8 +391,6 @@ class TestVAELatentAdaptiveImportanceResampling(TestVAESamplerBase):
     def on_test_start(self):
         super().on_test_start()
         hp = self.hparams
-        if hp.num_historical_proposals is not None:
-            raise NotImplementedError("historical proposals are not implemented")
         if hp.use_miss_model or hp.accept_reject_xm:
             raise NotImplementedError("missingness models (MNAR) are not implemented")
         _lib.proposal_transform_args(hp.var_proposal_temperature, hp.var_proposal_anneal_type_to_prior)
@@ -412,33 +410,50 @@ class TestVAELatentAdaptiveImportanceResampling(TestVAESamplerBase):
         alpha = min((iter + 10) / max_iter, 1)
         return log_weights * alpha
 
-    def _draws(self, B, K, R, D, second):
+    def _draws(self, B, K, R, D, second, use_hist=False, history=None):
+        """Injected draws of one iteration in the reference's call order: history window / chain
+        integers (:539-541), proposals, resampling (twice with store_latents), x_m."""
         src = self.draw_source
         if src is None:
             return None
         hp = self.hparams
+        d = {}
+        K_out, pad_to = K, None
+        if use_hist:
+            H = hp.num_historical_proposals
+            d["hist_r"] = src.randint_array(history.window_size(H), H)
+            if hp.resampling_scheme != 'glr':
+                d["hist_chain"] = src.randint_array(K, B)
+            K = K + H
+        elif (hp.no_historic_proposals_iterations is not None and hp.resampling_scheme == 'glr'
+              and hp.num_historical_proposals is not None):
+            pad_to = K + hp.num_historical_proposals
         I, Kp, Zd = hp.num_imp_samples, K + R, self.model.latent_dim
         bern = self.model.hparams.generator_distribution.name == "bern"
         # a Beta posterior is sampled by torch's Dirichlet sampler: the tape holds the samples
         beta = self.model.hparams.var_latent_distribution.name == "beta"
-        d = {"eps_z": src.beta(I, B, Kp, Zd) if beta else src.normal(I, B, Kp, Zd)}
-        G = Kp // hp.glr_cluster_size if hp.resampling_scheme == 'glr' else 1
+        d["eps_z"] = src.beta(I, B, Kp, Zd) if beta else src.normal(I, B, Kp, Zd)
+        G = (pad_to or Kp) // hp.glr_cluster_size if hp.resampling_scheme == 'glr' else 1
 
         def res():
             if hp.resampling_scheme in ('lr', 'ir'):  # one index per chain among its I candidates
                 return src.exponential(B * Kp, I) if hp.resampling_method == 'multinomial' else src.uniform(B, Kp, 1)
             if hp.resampling_method == 'multinomial':
-                return src.uniform64(B * G, Kp // G)
+                return src.uniform64(B * G, (pad_to or Kp) // G)
             return src.uniform(B, 1) if hp.resampling_scheme == 'gr' else src.uniform(B, G, 1)
         d["u_res"] = res()
         if second:
             d["u_res2"] = res()
-        d["eps_x"] = src.uniform(B, K, D) if bern else src.normal(B, K, D)
+        d["eps_x"] = src.uniform(B, K_out, D) if bern else src.normal(B, K_out, D)
         return d
 
     def sampler(self, X, M):
         hp = self.hparams
         B, K, D = X.shape
+        history = None
+        if hp.num_historical_proposals is not None:   # :1866-1870
+            history = ImputationHistoryQueue(max_history_length=hp.imputation_history_length, batch_shape=X.shape,
+                                             dtype=torch.float32, device=X.device)
         clip_min = clip_max = None
         if hp.clip_imputations:
             X_temp = X[:, 0].clone()
@@ -456,6 +471,8 @@ class TestVAELatentAdaptiveImportanceResampling(TestVAESamplerBase):
                              "eps_x": self.draw_source.normal(B, K, D)}
                 X, Z_imp = pseudo_gibbs_iteration(self.model, X, M, rng=self._rng(), draws=draws, inplace=True)
                 self._next_iteration()
+                if history is not None:
+                    history.enqueue_batch(X)
                 yield {'X': X, 'Z': Z_imp.clone(), 'is_ess': 0., 'is_ess_not_reduced': torch.zeros(B),
                        'total_num_props': 1.}
 
@@ -466,22 +483,29 @@ class TestVAELatentAdaptiveImportanceResampling(TestVAESamplerBase):
             if hp.weight_transform == 'poly':
                 weight_transform = min((t + 10) / self.max_iterations, 1)
             R = hp.num_prior_replenish_proposals if t % hp.prior_replenish_iteration_frequency == 0 else 0
+            use_hist = (hp.no_historic_proposals_iterations is not None
+                        and (hp.num_pseudo_warmup_iterations + t) > hp.no_historic_proposals_iterations)
             ret = importance_resampling_gibbs_iteration(
                 self.model, X, M, hp.num_imp_samples, glr_cluster_size=hp.glr_cluster_size,
                 weighting=hp.weighting_scheme, resampling_method=hp.resampling_method,
                 resampling_scheme=hp.resampling_scheme, num_prior_replenish_proposals=R,
+                use_historical_proposals=use_hist, num_historical_proposals=hp.num_historical_proposals,
+                history=history,
                 weight_transform=weight_transform, return_resampled_latents=bool(hp.store_latents),
                 var_proposal_temperature=hp.var_proposal_temperature,
                 var_proposal_anneal_type_to_prior=hp.var_proposal_anneal_type_to_prior,
-                rng=self._rng(), draws=self._draws(B, K, R, D, bool(hp.store_latents)),
+                rng=self._rng(), draws=self._draws(B, K, R, D, bool(hp.store_latents), use_hist, history),
                 clip_min=clip_min, clip_max=clip_max, inplace=True)
             self._next_iteration()
+            if history is not None:   # :1961-1962
+                history.enqueue_batch(ret[0])
             X, ess, transformed_ess, perplexity, total_num_props, norm_log_weights, Z_prop, log_weights = ret[:8]
             latents = ret[9].clone() if hp.store_latents else None  # (the reference fails without store_latents)
 
             if hp.resample_final_imps:
                 if self._proposals is None:
-                    if hp.prior_replenish_iteration_frequency != 1 and hp.num_prior_replenish_proposals > 0:
+                    if ((hp.prior_replenish_iteration_frequency != 1 and hp.num_prior_replenish_proposals > 0)
+                            or hp.no_historic_proposals_iterations is not None):
                         raise NotImplementedError("final resampling with a varying number of proposals")
                     self._proposals = (torch.empty((T,) + tuple(Z_prop.shape), device=X.device),
                                        torch.empty((T,) + tuple(log_weights.shape), device=X.device))

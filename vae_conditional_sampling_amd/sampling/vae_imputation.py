@@ -50,8 +50,6 @@ def importance_resampling_gibbs_iteration(model, X, M, num_imp_samples, *, glr_c
     views of the model's workspace and are overwritten by the next call (clone to keep)."""
     _check_common(miss_model, accept_reject_xm, data_channel_dim)
     _lib.proposal_transform_args(var_proposal_temperature, var_proposal_anneal_type_to_prior)
-    if use_historical_proposals:
-        raise NotImplementedError("historical proposals are not implemented")
     if weighting not in ("dmis", "dmis_within_groups", "smis"):
         raise NotImplementedError()
     if resampling_scheme not in ("gr", "glr", "lr", "ir"):
@@ -64,15 +62,44 @@ def importance_resampling_gibbs_iteration(model, X, M, num_imp_samples, *, glr_c
         assert glr_cluster_size is not None and glr_cluster_size > 1
     B, K, D = X.shape
     R = int(num_prior_replenish_proposals)
-    ws = engine.lair_workspace(model, B, K, R, int(num_imp_samples), X.device)
-    cfg = engine.lair_cfg(model, ws, weighting=weighting, scheme=resampling_scheme, method=resampling_method,
-                          cluster_size=glr_cluster_size, weight_alpha=weight_transform,
-                          temperature=var_proposal_temperature, anneal_type=var_proposal_anneal_type_to_prior)
     X_new = X if inplace else X.clone()
     if not X_new.is_contiguous():
         X_new = X_new.contiguous()
-    engine.lair_step(model, ws, X_new, engine.mask_u8(M), cfg, rng=rng, draws=draws,
-                     return_resampled_latents=return_resampled_latents, clip_min=clip_min, clip_max=clip_max)
+    H, pad_to, X_in = 0, 0, X_new
+    if use_historical_proposals is not None and use_historical_proposals:
+        # H stratified samples of the history join the K chains as proposals (:504-545)
+        from .utils import glr_history_chain_idx
+        H = int(num_historical_proposals)
+        d = draws or {}
+        w = history.window_size(H)
+        if d.get("hist_r") is not None:
+            r = [int(v) for v in d["hist_r"]]
+        else:  # common to the whole batch, like the reference's single randint call
+            import random
+            seed = ((rng.seed if rng is not None else 0) << 20) ^ (rng.iteration if rng is not None else 0)
+            r = [random.Random(seed * 64 + h).randrange(w) for h in range(H)]
+        slots = history.slots_from_window_draws(r, H)
+        hist_ws = model.__dict__.setdefault("_cs_hist_concat", {})
+        key = (B, K, H, D, str(X.device))
+        if key not in hist_ws:
+            hist_ws.clear()
+            hist_ws[key] = torch.empty(B, K + H, D, device=X.device, dtype=torch.float32)
+        if resampling_scheme == 'glr':
+            X_in = history.concat_history(X_new, slots, chain_of_proposal=glr_history_chain_idx(K, H, glr_cluster_size),
+                                          out=hist_ws[key])
+        else:
+            X_in = history.concat_history(X_new, slots, chain_of_example=d.get("hist_chain"), rng=rng, out=hist_ws[key])
+    elif use_historical_proposals is not None and resampling_scheme == 'glr' and num_historical_proposals is not None:
+        pad_to = K + int(num_historical_proposals)   # :546-548
+    ws = engine.lair_workspace(model, B, K + H, R, int(num_imp_samples), X.device, slots=pad_to or None)
+    cfg = engine.lair_cfg(model, ws, weighting=weighting, scheme=resampling_scheme, method=resampling_method,
+                          cluster_size=glr_cluster_size, weight_alpha=weight_transform,
+                          temperature=var_proposal_temperature, anneal_type=var_proposal_anneal_type_to_prior)
+    cfg.K_impute = K if H else 0
+    cfg.glr_pad_to = pad_to
+    engine.lair_step(model, ws, X_in, engine.mask_u8(M), cfg, rng=rng, draws=draws,
+                     return_resampled_latents=return_resampled_latents, clip_min=clip_min, clip_max=clip_max,
+                     X_out=X_new if H else None)
     acceptance_x = torch.tensor(1.)
     out = (X_new, ws.stats[0], ws.stats[1], ws.stats[2], ws.I * ws.Kp, ws.norm_log_w, ws.Z, ws.log_w, acceptance_x)
     if return_resampled_latents:

@@ -171,3 +171,52 @@ def test_history_queue_host_logic_and_glr_chain_index():
             assert w == ref.window(H)
             r = [(step * 5 + h * 3) % w for h in range(H)]
             assert q.slots_from_window_draws(r, H) == ref.slots(torch.tensor(r), H).tolist()
+
+
+import enum as _enum
+
+
+class _TrainingOnlyDist(_enum.Enum):
+    normal_with_eps = 1
+
+
+class _TrainingOnlyNet(torch.nn.Module):   # stands for a class of the training code that the reader must not need
+    def __init__(self):
+        super().__init__()
+        self.l = torch.nn.Linear(3, 2)
+
+
+def test_lightning_checkpoint_reader_executes_nothing_from_the_file(tmp_path):
+    """A checkpoint as the reference's training writes it: state_dict next to hyper_parameters that
+    pickle nn.Module instances and enums (vae.py:99-122).  weights_only loading refuses such a file;
+    the reader returns the state_dict without importing or constructing any class the file names."""
+    import collections
+    import pickle
+    from vae_conditional_sampling_amd.models import VAE, ResidualFCNetwork
+    from vae_conditional_sampling_amd.utils.checkpoint import load_state_dict_from_checkpoint
+    Dist = _TrainingOnlyDist
+    vae = VAE(ResidualFCNetwork(4, 14, 1, 64), "normal_with_eps", ResidualFCNetwork(7, 8, 2, 64), "normal_with_eps")
+    sd = collections.OrderedDict((k, v.clone()) for k, v in vae.state_dict().items())
+    ckpt = {"epoch": 7, "global_step": 123, "pytorch-lightning_version": "1.6.5", "state_dict": sd,
+            "hyper_parameters": {"generator_network": _TrainingOnlyNet(), "generator_distribution": Dist.normal_with_eps,
+                                 "lr_generator": 1e-3},
+            "optimizer_states": [{"state": {0: {"exp_avg": torch.randn(2, 3)}}, "param_groups": [{"lr": 1e-3}]}],
+            "callbacks": {"ModelCheckpoint": {"best_model_score": torch.tensor(1.5)}}}
+    path = str(tmp_path / "epoch=7-step=123.ckpt")
+    torch.save(ckpt, path)
+    with pytest.raises(pickle.UnpicklingError):
+        torch.load(path, map_location="cpu", weights_only=True)
+    got = load_state_dict_from_checkpoint(path)
+    assert list(got.keys()) == list(sd.keys())
+    assert all(torch.equal(got[k], sd[k]) and got[k].dtype == sd[k].dtype for k in sd)
+    vae2 = VAE(ResidualFCNetwork(4, 14, 1, 64), "normal_with_eps", ResidualFCNetwork(7, 8, 2, 64), "normal_with_eps")
+    vae2.load_state_dict(got, strict=True)
+    # a bare state dict (weights_only succeeds) and a non-checkpoint are handled too
+    bare = str(tmp_path / "bare.pt")
+    torch.save(sd, bare)
+    assert torch.equal(load_state_dict_from_checkpoint(bare)["generator_network.final_layer.bias"],
+                       sd["generator_network.final_layer.bias"])
+    bad = str(tmp_path / "bad.ckpt")
+    torch.save({"epoch": 1}, bad)
+    with pytest.raises(ValueError):
+        load_state_dict_from_checkpoint(bad)

@@ -25,6 +25,7 @@ import yaml
 from .data import MissingDataModule
 from .models import VAE, ResidualFCNetwork, ResNetDecoder, ResNetEncoder
 from .sampling import test_step_vae_sampling
+from .utils.checkpoint import load_state_dict_from_checkpoint
 from .utils.hparams import AttrDict
 
 
@@ -121,8 +122,7 @@ def run(cfg, *, device=None, rank=0, world_size=1):
     else:
         ckpt = find_checkpoint(cfg["model_path"], cfg.get("load_best"))
         print("Model path:", ckpt)
-        obj = torch.load(ckpt, map_location="cpu", weights_only=True)
-        model.load_state_dict(obj.get("state_dict", obj), strict=True)
+        model.load_state_dict(load_state_dict_from_checkpoint(ckpt), strict=True)
     tester.set_model(model)
     tester.set_datamodule(datamodule)
     datamodule.set_model(model)

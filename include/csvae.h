@@ -92,12 +92,14 @@ int cs_mlp_forward(const cs_mlp_t* net, const float* x, int64_t rows, float* y, 
  * ResNetDecoder.forward :259-277, DecoderBlock :166-184, Interpolate :14-22) and MLPs wider
  * than the fused kernel covers (toy configuration, hidden 512).  The caller describes the
  * network as a list of layers over numbered activation buffers; BatchNorm (eval mode) is
- * folded into the convolution weights and a bias by the caller, Dropout is the identity.
+ * folded into the convolution / linear weights and a bias by the caller, Dropout is the identity.
  * Activations are NHWC ([row, y, x, channel]); weights are given in torch's layouts
  * (convolution [cout][cin][kh][kw], linear [out][in]) and repacked by the library.
  * The handle is a cs_mlp_t: every entry point that takes an encoder / decoder accepts it.
  */
-enum { CS_OP_CONV = 1, CS_OP_LINEAR = 2, CS_OP_AVGPOOL = 3, CS_OP_RESIZE = 4 };
+enum { CS_OP_CONV = 1, CS_OP_LINEAR = 2, CS_OP_AVGPOOL = 3, CS_OP_RESIZE = 4,
+       CS_OP_LAYERNORM = 5 /* nn.LayerNorm(cin), eps 1e-5, weight at w_off, bias at b_off, optional ReLU:
+                              residual blocks with use_layer_norm (irwg/models/neural_nets.py:95-100) */ };
 /* buffer ids: 0 = network input [rows,in_dim], 1..4 = scratch, 5 = network output [rows,out_dim] */
 enum { CS_NET_NBUF = 6, CS_NET_BUF_IN = 0, CS_NET_BUF_OUT = 5 };
 typedef struct {

@@ -30,8 +30,16 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 def ref_resfc(ns, w):
     H, in_dim = w["W0"].shape
     out_dim = w["Wf"].shape[0]
-    net = ns.neural_nets.ResidualFCNetwork(in_dim, out_dim, len(w["blocks"]), H)
+    norms = w.get("norms")
+    kind = norms[0]["kind"] if norms else None
+    net = ns.neural_nets.ResidualFCNetwork(in_dim, out_dim, len(w["blocks"]), H, use_layer_norm=kind == "layer",
+                                           use_batch_norm=kind == "batch")
     with torch.no_grad():
+        for blk, n in zip(net.blocks, norms or []):
+            mod = blk.layer_norm if kind == "layer" else blk.batch_norm
+            mod.weight.copy_(n["weight"]); mod.bias.copy_(n["bias"])
+            if kind == "batch":
+                mod.running_mean.copy_(n["mean"]); mod.running_var.copy_(n["var"])
         net.initial_layer.weight.copy_(w["W0"]); net.initial_layer.bias.copy_(w["b0"])
         for blk, (W1, b1, W2, b2) in zip(net.blocks, w["blocks"]):
             blk.linear_layers[0].weight.copy_(W1); blk.linear_layers[0].bias.copy_(b1)
@@ -54,6 +62,11 @@ def flat_weights(prefix, w):
     for i, (W1, b1, W2, b2) in enumerate(w["blocks"]):
         d[f"{prefix}_blk{i}_W1"] = W1.numpy(); d[f"{prefix}_blk{i}_b1"] = b1.numpy()
         d[f"{prefix}_blk{i}_W2"] = W2.numpy(); d[f"{prefix}_blk{i}_b2"] = b2.numpy()
+    for i, n in enumerate(w.get("norms") or []):
+        d[f"{prefix}_norm_kind"] = np.array(n["kind"])
+        for k in ("weight", "bias", "mean", "var"):
+            if k in n:
+                d[f"{prefix}_norm{i}_{k}"] = n[k].numpy()
     return d
 
 
@@ -81,9 +94,9 @@ def make_inputs(B, K, D, seed, miss=0.5):
 # ----------------------------------------------------------------------------------------
 def case_lair(ns, name, *, B, K, R, I, D, Zd, H, nb_enc, nb_dec, seed, scheme="gr",
               weighting="dmis", method="multinomial", cluster=None, resampled_latents=False,
-              iters=2, temperature=None, anneal=None, latent_dist="normal_with_eps"):
-    enc = O.make_resfc_weights(D, 2 * Zd, nb_enc, H, seed)
-    dec = O.make_resfc_weights(Zd, 2 * D, nb_dec, H, seed + 1)
+              iters=2, temperature=None, anneal=None, latent_dist="normal_with_eps", norm=None):
+    enc = O.make_resfc_weights(D, 2 * Zd, nb_enc, H, seed, norm=norm)
+    dec = O.make_resfc_weights(Zd, 2 * D, nb_dec, H, seed + 1, norm=norm)
     vae = ref_vae(ns, enc, dec, latent_dist=latent_dist)
     X, M = make_inputs(B, K, D, seed + 2)
     fx = dict(flat_weights("enc", enc)); fx.update(flat_weights("dec", dec))
@@ -371,6 +384,20 @@ def case_lair_sampler(ns, name, *, B, K, R, D, Zd, H, seed, T, n_final=None, fre
     print(f"[ok] {name}")
 
 
+def case_mlp_norm(ns, name, *, in_dim, out_dim, nb, H, rows, seed, norm):
+    """ResidualFCNetwork.forward with LayerNorm / BatchNorm residual blocks (neural_nets.py:87-103), eval mode."""
+    w = O.make_resfc_weights(in_dim, out_dim, nb, H, seed, norm=norm)
+    net = ref_resfc(ns, w).eval()
+    x = torch.randn(3, rows, in_dim, generator=torch.Generator().manual_seed(seed + 1))
+    with torch.no_grad():
+        y = net(x)
+    assert torch.equal(y, O.resfc_forward(w, x)), "forward not bitwise equal"
+    fx = dict(flat_weights("net", w))
+    fx.update(x=x.numpy(), y=y.numpy())
+    np.savez_compressed(os.path.join(GOLDEN, f"{name}.npz"), **fx)
+    print(f"[ok] {name}")
+
+
 def case_metrics(ns, name, *, B, K, D, Zd, H, seed):
     """Per-iteration diagnostics (irwg/sampling/imputation_metrics.py:85-102,133-143,200-213)."""
     import importlib
@@ -413,6 +440,11 @@ def main():
                nkpc=4, cluster=5, R=5)
     case_acmwg(ns, "acmwg_pg_warmup", B=4, K=3, D=7, Zd=3, H=64, seed=808, warmup="pseudo_gibbs", W=3, T=10, p=0.05)
     case_acmwg(ns, "acmwg_nowarmup_noprior", B=4, K=2, D=6, Zd=3, H=64, seed=909, warmup="none", W=0, T=8, p=0.0)
+    case_mlp_norm(ns, "mlp_layernorm", in_dim=11, out_dim=10, nb=2, H=64, rows=9, seed=545, norm="layer")
+    case_mlp_norm(ns, "mlp_layernorm_h256", in_dim=43, out_dim=64, nb=2, H=256, rows=5, seed=555, norm="layer")
+    case_mlp_norm(ns, "mlp_batchnorm", in_dim=11, out_dim=10, nb=2, H=64, rows=9, seed=565, norm="batch")
+    case_lair(ns, "lair_layernorm_nets", B=5, K=4, R=1, I=1, D=11, Zd=5, H=64, nb_enc=2, nb_dec=1, seed=575, norm="layer")
+    case_lair(ns, "lair_batchnorm_nets", B=5, K=4, R=1, I=1, D=11, Zd=5, H=64, nb_enc=1, nb_dec=2, seed=585, norm="batch")
     check_single_sample_multinomial()
     case_lair(ns, "lair_lr_mult", B=5, K=3, R=1, I=4, D=9, Zd=4, H=64, nb_enc=1, nb_dec=1, seed=464, scheme="lr",
               weighting="smis", resampled_latents=True)

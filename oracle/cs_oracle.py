@@ -47,11 +47,13 @@ LOG_SQRT_2PI = math.log(math.sqrt(2 * math.pi))
 # --------------------------------------------------------------------------------------
 # networks
 # --------------------------------------------------------------------------------------
-def make_resfc_weights(in_dim, out_dim, num_blocks, hidden, seed):
+def make_resfc_weights(in_dim, out_dim, num_blocks, hidden, seed, norm=None):
     """Random weights with torch's default nn.Linear initialisation (kaiming-uniform,
     a=sqrt(5)) for a residual MLP of the reference's shape.  Returns a dict of float32
     torch tensors: W0[H,in] b0[H]; blocks: list of (W1[H,H], b1[H], W2[H,H], b2[H]);
-    Wf[out,H] bf[out]."""
+    Wf[out,H] bf[out].  ``norm`` = 'layer' / 'batch' adds 'norms': per block the parameters of the
+    normalisation after the block's first linear layer (neural_nets.py:81-85), drawn at random so
+    that the affine part and the running statistics matter."""
     g = torch.Generator().manual_seed(seed)
 
     def lin(o, i):
@@ -67,7 +69,17 @@ def make_resfc_weights(in_dim, out_dim, num_blocks, hidden, seed):
         W2, b2 = lin(hidden, hidden)
         blocks.append((W1, b1, W2, b2))
     Wf, bf = lin(out_dim, hidden)
-    return {"W0": W0, "b0": b0, "blocks": blocks, "Wf": Wf, "bf": bf}
+    w = {"W0": W0, "b0": b0, "blocks": blocks, "Wf": Wf, "bf": bf}
+    if norm is not None:
+        norms = []
+        for _ in range(num_blocks):
+            n = {"kind": norm, "weight": 0.5 + torch.rand(hidden, generator=g), "bias": 0.2 * torch.randn(hidden, generator=g)}
+            if norm == "batch":
+                n["mean"] = 0.3 * torch.randn(hidden, generator=g)
+                n["var"] = 0.5 + torch.rand(hidden, generator=g)
+            norms.append(n)
+        w["norms"] = norms
+    return w
 
 
 def net_input_dim(w):
@@ -87,8 +99,18 @@ def resfc_forward(w, x):
         from . import cs_oracle_conv  # weight dicts of the convolutional nets carry their own forward
         return cs_oracle_conv.net_forward(w, x)
     h = F.relu(F.linear(x, w["W0"], w["b0"]))
-    for (W1, b1, W2, b2) in w["blocks"]:
-        t = F.relu(F.linear(h, W1, b1))
+    norms = w.get("norms") or [None] * len(w["blocks"])
+    for (W1, b1, W2, b2), n in zip(w["blocks"], norms):
+        t = F.linear(h, W1, b1)
+        if n is not None:   # neural_nets.py:90-99, eval mode; applied on the 2-d view
+            H = t.shape[-1]
+            t2 = t.reshape(-1, H)
+            if n["kind"] == "layer":
+                t2 = F.layer_norm(t2, (H,), n["weight"], n["bias"], 1e-5)
+            else:
+                t2 = F.batch_norm(t2, n["mean"], n["var"], n["weight"], n["bias"], False, 0.1, 1e-5)
+            t = t2.reshape(t.shape)
+        t = F.relu(t)
         h = F.relu(h + F.linear(t, W2, b2))
     return F.linear(h, w["Wf"], w["bf"])
 

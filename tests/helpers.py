@@ -20,8 +20,13 @@ def weights_from_fixture(fx, prefix):
     t = lambda k: torch.from_numpy(fx[k])
     blocks = [(t(f"{prefix}_blk{i}_W1"), t(f"{prefix}_blk{i}_b1"), t(f"{prefix}_blk{i}_W2"), t(f"{prefix}_blk{i}_b2"))
               for i in range(nb)]
-    return {"W0": t(f"{prefix}_W0"), "b0": t(f"{prefix}_b0"), "blocks": blocks,
-            "Wf": t(f"{prefix}_Wf"), "bf": t(f"{prefix}_bf")}
+    w = {"W0": t(f"{prefix}_W0"), "b0": t(f"{prefix}_b0"), "blocks": blocks,
+         "Wf": t(f"{prefix}_Wf"), "bf": t(f"{prefix}_bf")}
+    if f"{prefix}_norm_kind" in fx:   # normalisation after the first linear layer of every block
+        kind = str(fx[f"{prefix}_norm_kind"])
+        w["norms"] = [dict(kind=kind, **{k: t(f"{prefix}_norm{i}_{k}") for k in ("weight", "bias", "mean", "var")
+                                         if f"{prefix}_norm{i}_{k}" in fx}) for i in range(nb)]
+    return w
 
 
 def rel_err(a, b):
@@ -41,13 +46,23 @@ def assert_close(a, b, what, rtol=RTOL):
 
 def make_model(enc_w, dec_w, latent_dist="normal_with_eps", gen_dist="normal_with_eps", device="cuda"):
     """Product-side VAE (HIP engine) holding the given weight dicts."""
-    from vae_conditional_sampling_amd.models import ResidualFCNetwork, VAE
-    H, D = enc_w["W0"].shape
-    Zd2 = enc_w["Wf"].shape[0]
-    enc = ResidualFCNetwork(D, Zd2, len(enc_w["blocks"]), H).load_weight_dict(enc_w)
-    dec = ResidualFCNetwork(dec_w["W0"].shape[1], dec_w["Wf"].shape[0], len(dec_w["blocks"]),
-                            dec_w["W0"].shape[0]).load_weight_dict(dec_w)
-    return VAE(dec, gen_dist, enc, latent_dist).to(device)
+    from vae_conditional_sampling_amd.models import VAE
+    return VAE(make_net(dec_w), gen_dist, make_net(enc_w), latent_dist).to(device)
+
+
+def make_net(w):
+    """Product-side residual MLP holding a weight dict (with its block normalisations, if any)."""
+    from vae_conditional_sampling_amd.models import ResidualFCNetwork
+    kind = w["norms"][0]["kind"] if w.get("norms") else None
+    net = ResidualFCNetwork(w["W0"].shape[1], w["Wf"].shape[0], len(w["blocks"]), w["W0"].shape[0],
+                            use_layer_norm=kind == "layer", use_batch_norm=kind == "batch").load_weight_dict(w)
+    with torch.no_grad():
+        for blk, n in zip(net.blocks, w.get("norms") or []):
+            mod = blk.layer_norm if kind == "layer" else blk.batch_norm
+            mod.weight.copy_(n["weight"]); mod.bias.copy_(n["bias"])
+            if kind == "batch":
+                mod.running_mean.copy_(n["mean"]); mod.running_var.copy_(n["var"])
+    return net
 
 
 def seeded_inputs(B, K, D, seed, miss=0.5):

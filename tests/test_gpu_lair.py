@@ -19,7 +19,8 @@ pytestmark = pytest.mark.gpu
 
 LAIR_CASES = ["lair_gr_mult_small", "lair_gr_mult_i2_lat", "lair_gr_mult_noreplenish", "lair_gr_syst",
               "lair_glr_groups", "lair_miniboone_shape", "lair_tempered_annealed", "lair_annealed_025_normal",
-              "lair_tempered", "lair_lr_mult", "lair_lr_syst", "lair_ir_mult", "lair_ir_mult_i6", "lair_ir_syst"]
+              "lair_tempered", "lair_lr_mult", "lair_lr_syst", "lair_ir_mult", "lair_ir_mult_i6", "lair_ir_syst",
+              "lair_layernorm_nets", "lair_batchnorm_nets"]
 
 
 @pytest.fixture(scope="module")
@@ -42,6 +43,20 @@ def test_mlp_forward_matches_oracle(O, shape):
     y3 = net(x.cuda().reshape(1, rows, in_dim))
     assert y3.shape == (1, rows, out_dim)
     assert torch.equal(y3[0], y)
+
+
+@pytest.mark.parametrize("name", ["mlp_layernorm", "mlp_layernorm_h256", "mlp_batchnorm"])
+def test_mlp_with_block_normalisation_matches_reference_golden(name):
+    """Residual blocks with LayerNorm (row-wise launch between the block's GEMMs) or eval-mode
+    BatchNorm (folded into the first linear layer, fused kernel) against the reference's forward."""
+    from tests.helpers import make_net
+    fx = load_golden(name)
+    net = make_net(weights_from_fixture(fx, "net")).cuda().eval()
+    y = net(torch.from_numpy(fx["x"]).cuda())
+    assert_close(y, fx["y"], "forward")
+    sd = net.state_dict()
+    kind = str(fx["net_norm_kind"])
+    assert ("blocks.0.layer_norm.weight" if kind == "layer" else "blocks.0.batch_norm.running_var") in sd
 
 
 @pytest.mark.parametrize("name", LAIR_CASES)

@@ -66,8 +66,11 @@ def test_models_mirror_reference_state_dict_layout():
     assert "generator_network.final_layer.weight" in keys
     assert vae.state_dict()["generator_network.final_layer.weight"].shape == (86, 256)
     assert vae.hparams.generator_distribution is DISTRIBUTION.normal_with_eps and vae.latent_dim == 32
+    ln = ResidualFCNetwork(4, 4, 1, 64, use_layer_norm=True)
+    bn = ResidualFCNetwork(4, 4, 1, 64, use_batch_norm=True)
+    assert "blocks.0.layer_norm.bias" in ln.state_dict() and "blocks.0.batch_norm.num_batches_tracked" in bn.state_dict()
     with pytest.raises(NotImplementedError):
-        ResidualFCNetwork(4, 4, 1, 64, use_layer_norm=True)
+        ResidualFCNetwork(4, 4, 1, 64, activation="tanh")
     p = vae.split_params(torch.arange(12.).reshape(2, 6), 2)
     assert p.shape == (2, 2, 3) and torch.equal(vae.join_params(p), torch.arange(12.).reshape(2, 6))
 

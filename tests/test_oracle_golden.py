@@ -15,7 +15,8 @@ from tests.helpers import assert_close, load_golden, weights_from_fixture
 
 LAIR_CASES = ["lair_gr_mult_small", "lair_gr_mult_i2_lat", "lair_gr_mult_noreplenish", "lair_gr_syst",
               "lair_glr_groups", "lair_miniboone_shape", "lair_tempered_annealed", "lair_annealed_025_normal",
-              "lair_tempered", "lair_lr_mult", "lair_lr_syst", "lair_ir_mult", "lair_ir_mult_i6", "lair_ir_syst"]
+              "lair_tempered", "lair_lr_mult", "lair_lr_syst", "lair_ir_mult", "lair_ir_mult_i6", "lair_ir_syst",
+              "lair_layernorm_nets", "lair_batchnorm_nets"]
 
 
 @pytest.mark.parametrize("name", LAIR_CASES)
@@ -142,3 +143,10 @@ def test_oracle_lair_sampler_with_history(name):
     for t, o in enumerate(outs):
         assert_close(o["X"], fx["X_seq"][t], f"X[{t}]")
         assert_close(o["Z"], fx[f"Z_t{t}"], f"Z[{t}]")
+
+
+@pytest.mark.parametrize("name", ["mlp_layernorm", "mlp_layernorm_h256", "mlp_batchnorm"])
+def test_oracle_mlp_with_block_normalisation(name):
+    fx = load_golden(name)
+    w = weights_from_fixture(fx, "net")
+    assert_close(O.resfc_forward(w, torch.from_numpy(fx["x"])), fx["y"], "forward")

@@ -47,7 +47,7 @@ class cs_mlp_desc(C.Structure):
                 ("hidden", C.c_int32), ("out_split", C.c_int32)]
 
 
-CS_OP_CONV, CS_OP_LINEAR, CS_OP_AVGPOOL, CS_OP_RESIZE = 1, 2, 3, 4
+CS_OP_CONV, CS_OP_LINEAR, CS_OP_AVGPOOL, CS_OP_RESIZE, CS_OP_LAYERNORM = 1, 2, 3, 4, 5
 CS_NET_BUF_IN, CS_NET_BUF_OUT = 0, 5
 
 
@@ -240,6 +240,11 @@ class ProgramBuilder:
     def linear(self, src, dst, weight, bias, *, relu=False, res=-1):
         out, inp = weight.shape
         self.layers.append(cs_layer_desc(CS_OP_LINEAR, src, dst, res, int(relu), inp, out, 1, 1, 1, 1, 1, 1, 0, 1, 0, 0,
+                                         self._add(weight), self._add(bias)))
+
+    def layernorm(self, src, dst, weight, bias, *, relu=False):
+        n = weight.numel()
+        self.layers.append(cs_layer_desc(CS_OP_LAYERNORM, src, dst, -1, int(relu), n, n, 1, 1, 1, 1, 1, 1, 0, 1, 0, 0,
                                          self._add(weight), self._add(bias)))
 
     def avgpool(self, src, dst, *, channels, hin, win):

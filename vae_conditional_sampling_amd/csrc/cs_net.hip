@@ -379,6 +379,35 @@ __global__ void __launch_bounds__(256) cs_conv_direct_kernel(const CsConvArgs a)
 }
 
 // AdaptiveAvgPool2d((1,1)) over NHWC: one thread per (row, channel).
+// nn.LayerNorm(features) over the last dimension (eps 1e-5, biased variance) with its affine
+// parameters, optional ReLU: the normalisation inside the reference's residual blocks
+// (irwg/models/neural_nets.py:95-100).  One wavefront per row.
+__global__ void __launch_bounds__(256) cs_layernorm_kernel(const float* in, float* out, int64_t rows, int n,
+                                                           const float* gamma, const float* beta, int relu) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const float* x = in + r * n;
+  float s = 0.0f;
+  for (int i = lane; i < n; i += 64) s += x[i];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  const float mean = s / (float)n;
+  float v = 0.0f;
+  for (int i = lane; i < n; i += 64) {
+    const float d = x[i] - mean;
+    v += d * d;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  const float rstd = 1.0f / sqrtf(v / (float)n + 1e-5f);
+  for (int i = lane; i < n; i += 64) {
+    float y = (x[i] - mean) * rstd * gamma[i] + beta[i];
+    if (relu) y = fmaxf(y, 0.0f);
+    out[r * n + i] = y;
+  }
+}
+
 __global__ void __launch_bounds__(256) cs_avgpool_kernel(const float* in, float* out, int64_t n, int hw, int c) {
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (idx >= n * c) return;
@@ -625,7 +654,10 @@ extern "C" int cs_net_create(const cs_layer_desc* layers, int32_t n_layers, cons
       d.hin = d.win = d.hout = d.wout = 1; d.ksize = 1; d.stride = 1; d.pad = 0; d.upsample = 1;
       d.in_nchw = d.out_nchw = 0;
     }
-    if (d.op < CS_OP_CONV || d.op > CS_OP_RESIZE) return fail("unknown op");
+    if (d.op == CS_OP_LAYERNORM) {
+      d.hin = d.win = d.hout = d.wout = 1; d.in_nchw = d.out_nchw = 0;
+    }
+    if (d.op < CS_OP_CONV || d.op > CS_OP_LAYERNORM) return fail("unknown op");
     if (d.src < 0 || d.src >= CS_NET_NBUF || d.dst < 1 || d.dst >= CS_NET_NBUF || d.src == d.dst) return fail("bad buffer id");
     if (d.res >= CS_NET_NBUF || d.res == d.dst) return fail("bad residual buffer id");
     if (d.cin < 1 || d.cout < 1 || d.hin < 1 || d.win < 1 || d.hout < 1 || d.wout < 1) return fail("bad layer shape");
@@ -642,6 +674,11 @@ extern "C" int cs_net_create(const cs_layer_desc* layers, int32_t n_layers, cons
       if (d.b_off >= 0 && d.b_off + d.cout > blob_floats) return fail("bias offset out of range");
       if (d.res >= 0 && d.out_nchw) return fail("residual with a channel-major output");
       if (d.b_off >= 0 && d.b_off % 4 != 0) return fail("bias offsets must be multiples of 4 floats");
+    } else if (d.op == CS_OP_LAYERNORM) {
+      if (d.cin != d.cout) return fail("channel counts must match");
+      if (d.res >= 0) return fail("no residual input on a layer norm");
+      if (d.w_off < 0 || d.w_off + d.cin > blob_floats || d.b_off < 0 || d.b_off + d.cin > blob_floats)
+        return fail("layer-norm weight / bias offset out of range");
     } else {
       if (d.cin != d.cout) return fail("channel counts must match");
       if (d.op == CS_OP_AVGPOOL && (d.hout != 1 || d.wout != 1)) return fail("average pool is global");
@@ -746,6 +783,9 @@ int cs_prog_launch(const CsMlpArgs& a, hipStream_t stream) {
       float* dst = d.dst == CS_NET_BUF_OUT ? raw : buf[d.dst];
       if (d.op == CS_OP_CONV || d.op == CS_OP_LINEAR) {
         if (int rc = launch_conv(*p, L, src, res, dst, rows, stream)) return rc;
+      } else if (d.op == CS_OP_LAYERNORM) {
+        hipLaunchKernelGGL(cs_layernorm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, src, dst, rows,
+                           d.cin, p->d_blob + d.w_off, p->d_blob + d.b_off, d.relu);
       } else if (d.op == CS_OP_AVGPOOL) {
         hipLaunchKernelGGL(cs_avgpool_kernel, dim3(blocks_for(rows * d.cin)), dim3(256), 0, stream, src, dst, rows,
                            d.hin * d.win, d.cin);

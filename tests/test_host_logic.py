@@ -223,3 +223,19 @@ def test_lightning_checkpoint_reader_executes_nothing_from_the_file(tmp_path):
     torch.save({"epoch": 1}, bad)
     with pytest.raises(ValueError):
         load_state_dict_from_checkpoint(bad)
+
+
+def test_async_npz_writer(tmp_path):
+    from vae_conditional_sampling_amd.utils.artifacts import AsyncNpzWriter
+    w = AsyncNpzWriter(workers=2, max_pending=2)
+    arrays = [np.random.default_rng(i).normal(size=(50, 40)).astype(np.float32) for i in range(5)]
+    for i, a in enumerate(arrays):
+        w.submit(str(tmp_path / f"imputations_{i}.npz"), imputations=a, data_idx=np.arange(50))
+    w.wait()
+    for i, a in enumerate(arrays):
+        f = np.load(tmp_path / f"imputations_{i}.npz")
+        assert np.array_equal(f["imputations"], a) and f["data_idx"].shape == (50,)
+    w.submit(str(tmp_path / "no_such_dir" / "x.npz"), a=arrays[0])     # errors surface in wait()
+    with pytest.raises(OSError):
+        w.wait()
+    w.close()

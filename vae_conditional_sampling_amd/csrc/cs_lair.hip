@@ -176,21 +176,37 @@ __global__ void __launch_bounds__(64) cs_lair_resample_kernel(const CsResampleAr
     if (a.cfg.weighting == CS_W_SMIS) {
       ql = comp(kp_s);
     } else {
-      float m = -INFINITY;
+      float m = -INFINITY, sum = 0.0f;
       int ncomp = 0;
-      for (int cc = 0; cc < a.mixc; ++cc) {
-        const int j = gm + a.mixG * cc;
-        if (j >= Kp) break;  // padded layout: this member does not exist
-        const float cj = comp(j);
-        m = fmaxf(m, cj);
-        ++ncomp;
-      }
-      if (!(fabsf(m) < INFINITY)) m = 0.0f;
-      float sum = 0.0f;
-      for (int cc = 0; cc < ncomp; ++cc) {
-        const int j = gm + a.mixG * cc;
-        const float cj = comp(j);
-        sum += expf(cj - m);
+      if (a.mixc <= 8) {
+        // small mixtures: every component density is evaluated once and kept in registers
+        float cv[8];
+#pragma unroll
+        for (int cc = 0; cc < 8; ++cc) {
+          const int j = gm + a.mixG * cc;
+          const bool on = cc < a.mixc && j < Kp;  // j >= Kp: padded layout, this member does not exist
+          cv[cc] = on ? comp(j) : -INFINITY;
+          ncomp += on ? 1 : 0;
+          m = fmaxf(m, cv[cc]);
+        }
+        if (!(fabsf(m) < INFINITY)) m = 0.0f;
+#pragma unroll
+        for (int cc = 0; cc < 8; ++cc)
+          if (cc < ncomp) sum += expf(cv[cc] - m);
+      } else {
+        for (int cc = 0; cc < a.mixc; ++cc) {
+          const int j = gm + a.mixG * cc;
+          if (j >= Kp) break;
+          const float cj = comp(j);
+          m = fmaxf(m, cj);
+          ++ncomp;
+        }
+        if (!(fabsf(m) < INFINITY)) m = 0.0f;
+        for (int cc = 0; cc < ncomp; ++cc) {
+          const int j = gm + a.mixG * cc;
+          const float cj = comp(j);
+          sum += expf(cj - m);
+        }
       }
       ql = logf(sum) + m - logf((float)ncomp);
     }

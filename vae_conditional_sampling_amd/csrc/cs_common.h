@@ -9,6 +9,23 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+#ifdef __HIPCC__
+// One 16-byte-per-lane global->LDS copy with the source addressed as scalar base + 32-bit lane
+// offset and the LDS destination base in M0.  Written as asm because the compiler's selection of the
+// builtin re-associates (base + constant) + lane offset into a 64-bit vector add per copy, and on this
+// library's matrix kernels every vector instruction displaces exact-f32 matrix work; here the per-copy
+// address arithmetic is scalar.  Every LDS-DMA copy of a kernel that uses it must go through this
+// function, which sets M0 itself.
+__device__ __forceinline__ void cs_dma16(const void* sbase, unsigned lane_off, unsigned lds_base) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %0"
+               :
+               : "s"(sbase), "v"(lane_off), "s"(lds_base)
+               : "memory");
+}
+__device__ __forceinline__ unsigned cs_scalar_u32(unsigned v) { return __builtin_amdgcn_readfirstlane(v); }
+#endif
+
+
 #define CS_LOG_SQRT_2PI 0.91893853320467274178f
 
 // ---- error reporting ---------------------------------------------------------------

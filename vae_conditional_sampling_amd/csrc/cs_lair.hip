@@ -16,6 +16,7 @@
 // deterministic-mixture proposal density and the resampling are both "within group" when the
 // corresponding option asks for it.
 // ----------------------------------------------------------------------------------------
+struct CsDiv { uint32_t mul, d; };
 struct CsResampleArgs {
   cs_lair_cfg cfg;
   cs_lair_bufs b;
@@ -26,7 +27,23 @@ struct CsResampleArgs {
   int NS;                // output slots of the resampling = G*c (K', or glr_pad_to when padded)
   int lds_per_wave;      // floats
   int E;                 // examples per wavefront
+  int q_stride;          // floats between the staged proposal parameters of consecutive examples
+  int z_stride;          // floats between staged latents of consecutive proposals
+  CsDiv dZd, dZq, dS, dKp, dNS, dDQ, dKimp, dMC, dmixG;  // divisors of the index arithmetic (Zq = Zd/4)
 };
+
+// Division of a small index by a launch constant: floor(t / d) = hi32(t * ceil(2^32 / d)), exact
+// while t * d < 2^32 (the host checks the ranges).  An integer division by a run-time value costs
+// ~40 instructions, and the staging / imputation loops of this kernel did three per element.
+__device__ __forceinline__ int cs_div(int t, const CsDiv& dv) {
+  return dv.d == 1u ? t : (int)__umulhi((unsigned)t, dv.mul);
+}
+static CsDiv cs_mkdiv(int d) {
+  CsDiv v;
+  v.d = (uint32_t)d;
+  v.mul = d > 1 ? (uint32_t)(((1ull << 32) + (uint64_t)d - 1) / (uint64_t)d) : 0u;
+  return v;
+}
 
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
@@ -50,51 +67,105 @@ __device__ __forceinline__ float wave_logsumexp(float x, bool in) {
 // E = floor(64/S) examples share a wavefront: lane = e*S + s.  Reductions over the proposals of
 // one example are loops of wave shuffles over its S lanes (S is small: 5..25 in the
 // configurations), so every lane does useful work.
+// VEC: Zd is a multiple of 4 and q / Z are 16-byte aligned, so staging and the density loops move
+// 4 latent dimensions per instruction.  The staged rows are padded (q_stride / 4 odd, z_stride =
+// Zd + 4, or odd strides without VEC) so that the examples / proposals of a wavefront fall into
+// different LDS banks.
+template <bool VEC>
 __global__ void __launch_bounds__(64) cs_lair_resample_kernel(const CsResampleArgs a) {
   extern __shared__ float lds[];
   const int lane = threadIdx.x;
   const int B = a.cfg.B, K = a.cfg.K, D = a.cfg.D, Zd = a.cfg.Zd, I = a.cfg.I;
   const int Kp = a.Kp, S = a.S, G = a.G, c = a.c, E = a.E, NS = a.NS;
+  const int QS = a.q_stride, ZS = a.z_stride;
   const int64_t b0 = (int64_t)blockIdx.x * E;            // first example of this wave
   const int ne = (int)((B - b0) < E ? (B - b0) : E);     // examples present
-  float* l_loc = lds;                      // [E][Kp*Zd]
-  float* l_2var = l_loc + E * Kp * Zd;     // [E][Kp*Zd]  1/(2*scale^2)
-  float* l_logs = l_2var + E * Kp * Zd;    // [E][Kp*Zd]  log(scale)
-  float* l_z = l_logs + E * Kp * Zd;       // [E][S][Zd+1]
-  int* l_idx = (int*)(l_z + E * S * (Zd + 1));  // [E][2*NS] resampled global indices (two draws)
+  float* l_loc = lds;                      // [E][QS]  (Kp*Zd used)
+  float* l_2var = l_loc + E * QS;          // [E][QS]  1/(2*scale^2)
+  float* l_logs = l_2var + E * QS;         // [E][QS]  log(scale)
+  float* l_z = l_logs + E * QS;            // [E][S][ZS]
+  int* l_idx = (int*)(l_z + E * S * ZS);   // [E][2*NS] resampled global indices (two draws)
+  float* l_c = (float*)(l_idx + E * 2 * NS);  // [E][S][mixc] component log-densities
+  const bool beta_q = a.cfg.latent_dist == CS_DIST_BETA;
+  // -DCS_RS_PROFILE (debug builds only, see tools/rs_phases.py): the wavefront's clock at the phase
+  // boundaries; the phase durations then overwrite the first entries of ess / tess / perplexity
+#ifdef CS_RS_PROFILE
+  unsigned long long T[9]; int tn = 0;
+#define CS_TICK() T[tn++] = __builtin_amdgcn_s_memtime()
+#else
+#define CS_TICK()
+#endif
+  CS_TICK();
 
   {
     const float* qb = a.b.q + b0 * Kp * 2 * Zd;
-    for (int t = lane; t < ne * Kp * Zd; t += 64) {
-      const int ej = t / Zd, d = t - ej * Zd;  // ej = e*Kp + j
-      const float loc = qb[ej * 2 * Zd + d], sc = qb[ej * 2 * Zd + Zd + d];
-      if (a.cfg.latent_dist == CS_DIST_BETA) {
-        // (loc, sc) = (alpha, beta): stage alpha-1, beta-1 and the log-normaliser of
-        // torch's Dirichlet.log_prob, lgamma(alpha+beta) - (lgamma(alpha) + lgamma(beta))
-        l_loc[t] = loc - 1.0f;
-        l_2var[t] = sc - 1.0f;
-        l_logs[t] = lgammaf(loc + sc) - (lgammaf(loc) + lgammaf(sc));
+    // (loc, sc) -> staged triple.  Beta: (alpha, beta) -> alpha-1, beta-1 and the log-normaliser of
+    // torch's Dirichlet.log_prob, lgamma(alpha+beta) - (lgamma(alpha) + lgamma(beta))
+    auto stage1 = [&](float loc, float sc, float& o0, float& o1, float& o2) {
+      if (beta_q) {
+        o0 = loc - 1.0f;
+        o1 = sc - 1.0f;
+        o2 = lgammaf(loc + sc) - (lgammaf(loc) + lgammaf(sc));
       } else {
-        l_loc[t] = loc;
-        l_2var[t] = 1.0f / (2.0f * (sc * sc));
-        l_logs[t] = logf(sc);
+        o0 = loc;
+        o1 = __builtin_amdgcn_rcpf(2.0f * (sc * sc));
+        o2 = cs_logf(sc);
       }
-    }
-    for (int t = lane; t < ne * S * Zd; t += 64) {
-      const int es = t / Zd, d = t - es * Zd;
-      const int e = es / S, s = es - e * S;
-      const int i = s / Kp, kp = s - i * Kp;
-      l_z[es * (Zd + 1) + d] = a.b.Z[(((int64_t)i * B + b0 + e) * Kp + kp) * Zd + d];
+    };
+    if (VEC) {
+      // one loop for both copies, so that the loads of q and Z share their round trips to memory
+      const int Zq = Zd >> 2;
+      const int nq = ne * Kp * Zq, nz = ne * S * Zq;
+#pragma unroll 2
+      for (int t = lane; t < nz; t += 64) {   // nz >= nq (S >= Kp)
+        const int es = cs_div(t, a.dZq), dq = t - es * Zq;   // es = e*S + s; for q: ej = e*Kp + j
+        const int e = cs_div(es, a.dS), s = es - e * S;
+        const int i = cs_div(s, a.dKp), kp = s - i * Kp;
+        const f32x4 zz = *(const f32x4*)(a.b.Z + (((int64_t)i * B + b0 + e) * Kp + kp) * Zd + 4 * dq);
+        const bool hq = t < nq;
+        const int eq = cs_div(es, a.dKp), j = es - eq * Kp;
+        f32x4 loc = {1.0f, 1.0f, 1.0f, 1.0f}, sc = loc;
+        if (hq) {
+          loc = *(const f32x4*)(qb + (int64_t)es * 2 * Zd + 4 * dq);
+          sc = *(const f32x4*)(qb + (int64_t)es * 2 * Zd + Zd + 4 * dq);
+        }
+        *(f32x4*)(l_z + es * ZS + 4 * dq) = zz;
+        if (hq) {
+          float o0[4], o1[4], o2[4];
+          stage1(loc.x, sc.x, o0[0], o1[0], o2[0]);
+          stage1(loc.y, sc.y, o0[1], o1[1], o2[1]);
+          stage1(loc.z, sc.z, o0[2], o1[2], o2[2]);
+          stage1(loc.w, sc.w, o0[3], o1[3], o2[3]);
+          const int o = eq * QS + j * Zd + 4 * dq;
+          *(f32x4*)(l_loc + o) = f32x4{o0[0], o0[1], o0[2], o0[3]};
+          *(f32x4*)(l_2var + o) = f32x4{o1[0], o1[1], o1[2], o1[3]};
+          *(f32x4*)(l_logs + o) = f32x4{o2[0], o2[1], o2[2], o2[3]};
+        }
+      }
+    } else {
+      for (int t = lane; t < ne * Kp * Zd; t += 64) {
+        const int ej = cs_div(t, a.dZd), d = t - ej * Zd;  // ej = e*Kp + j
+        const int e = cs_div(ej, a.dKp), j = ej - e * Kp;
+        const int o = e * QS + j * Zd + d;
+        stage1(qb[(int64_t)ej * 2 * Zd + d], qb[(int64_t)ej * 2 * Zd + Zd + d], l_loc[o], l_2var[o], l_logs[o]);
+      }
+      for (int t = lane; t < ne * S * Zd; t += 64) {
+        const int es = cs_div(t, a.dZd), d = t - es * Zd;
+        const int e = cs_div(es, a.dS), s = es - e * S;
+        const int i = cs_div(s, a.dKp), kp = s - i * Kp;
+        l_z[es * ZS + d] = a.b.Z[(((int64_t)i * B + b0 + e) * Kp + kp) * Zd + d];
+      }
     }
   }
   __syncthreads();
+  CS_TICK();
 
-  const int e_l = lane / S;                 // example slot of this lane
+  const int e_l = cs_div(lane, a.dS);       // example slot of this lane
   const int s = lane - e_l * S;             // proposal
   const bool act = e_l < ne;                // (lanes >= E*S have e_l >= E >= ne)
   const int base = act ? e_l * S : 0;       // first lane of this example
   const int64_t b = b0 + e_l;
-  const int i_s = s / Kp, kp_s = s - i_s * Kp;
+  const int i_s = cs_div(s, a.dKp), kp_s = s - i_s * Kp;
   // Resampling group of this proposal and its position inside the group.  gr / glr / lr: group
   // kp mod G, members in '(i c)' order (lr: G = K', c = 1, so the group of chain k holds its I
   // importance samples).  ir: the flattened '(i k)' axis is cut into K' runs of I consecutive
@@ -142,79 +213,96 @@ __global__ void __launch_bounds__(64) cs_lair_resample_kernel(const CsResampleAr
     return logf(seg_sum(expf(x - m), grouped)) + m;
   };
 
+  // requested here, consumed after the densities
+  const int64_t rho_s = ((int64_t)i_s * B + b) * Kp + kp_s;
+  const float gll = act ? a.b.gen_ll[rho_s] : 0.0f;
+
+  // ---- component log-densities: one work item per (example, proposal, component slot), spread
+  // over all 64 lanes (the proposals of the wave's examples alone would leave most lanes idle
+  // during the most expensive loop).  Components of proposal kp: j = kp mod mixG + mixG*cc, cc < mixc
+  // (smis: mixG = K', mixc = 1, so j = kp); j >= K' is a member that the padded layout lacks.
+  {
+    const int MC = a.mixc;
+    for (int t = lane; t < ne * S * MC; t += 64) {
+      const int es = cs_div(t, a.dMC), cc = t - es * MC;
+      const int e = cs_div(es, a.dS), s2 = es - e * S;
+      const int kp2 = s2 - cs_div(s2, a.dKp) * Kp;
+      const int j = kp2 - cs_div(kp2, a.dmixG) * a.mixG + a.mixG * cc;
+      float cj = -INFINITY;
+      if (j < Kp) {
+        // log-density of component j at the proposal, summed over the latent dimensions in order
+        const float* z = l_z + es * ZS;
+        const float* qloc = l_loc + e * QS + j * Zd;
+        const float* q2v = l_2var + e * QS + j * Zd;
+        const float* qls = l_logs + e * QS + j * Zd;
+        cj = 0.0f;
+        if (beta_q) {
+          for (int d = 0; d < Zd; ++d)
+            cj += (cs_xlogy(qloc[d], z[d]) + cs_xlogy(q2v[d], 1.0f - z[d])) + qls[d];
+        } else if (VEC) {
+          for (int d = 0; d < Zd; d += 4) {
+            const f32x4 zz = *(const f32x4*)(z + d);
+            const f32x4 lo = *(const f32x4*)(qloc + d);
+            const f32x4 iv = *(const f32x4*)(q2v + d);
+            const f32x4 ls = *(const f32x4*)(qls + d);
+            float df;
+            df = zz.x - lo.x; cj += -(df * df) * iv.x - ls.x - CS_LOG_SQRT_2PI;
+            df = zz.y - lo.y; cj += -(df * df) * iv.y - ls.y - CS_LOG_SQRT_2PI;
+            df = zz.z - lo.z; cj += -(df * df) * iv.z - ls.z - CS_LOG_SQRT_2PI;
+            df = zz.w - lo.w; cj += -(df * df) * iv.w - ls.w - CS_LOG_SQRT_2PI;
+          }
+        } else {
+          for (int d = 0; d < Zd; ++d) {
+            const float df = z[d] - qloc[d];
+            cj += -(df * df) * q2v[d] - qls[d] - CS_LOG_SQRT_2PI;
+          }
+        }
+      }
+      l_c[t] = cj;
+    }
+  }
+  __syncthreads();
+
   float lw = 0.0f;
   if (act) {
-    const float* z = l_z + (e_l * S + s) * (Zd + 1);
-    const float* qloc = l_loc + e_l * Kp * Zd;
-    const float* q2v = l_2var + e_l * Kp * Zd;
-    const float* qls = l_logs + e_l * Kp * Zd;
-    const bool beta = a.cfg.latent_dist == CS_DIST_BETA;
+    const float* z = l_z + (e_l * S + s) * ZS;
     float pl = 0.0f;
     if (a.cfg.prior == CS_PRIOR_UNIFORM) {
       // Uniform(0, 1 + 1e-8).log_prob (the upper bound is 1 in float32): log(1[0 <= z < 1]) - log(1)
       for (int d = 0; d < Zd; ++d) pl += (z[d] >= 0.0f && z[d] < 1.0f) ? 0.0f : -INFINITY;
+    } else if (VEC) {
+      for (int d = 0; d < Zd; d += 4) {
+        const f32x4 zz = *(const f32x4*)(z + d);
+        pl += cs_stdnormal_logpdf(zz.x);
+        pl += cs_stdnormal_logpdf(zz.y);
+        pl += cs_stdnormal_logpdf(zz.z);
+        pl += cs_stdnormal_logpdf(zz.w);
+      }
     } else {
       for (int d = 0; d < Zd; ++d) pl += cs_stdnormal_logpdf(z[d]);
     }
-    // log-density of component j at this proposal, summed over the latent dimensions
-    auto comp = [&](int j) {
-      float cj = 0.0f;
-      if (beta) {
-        for (int d = 0; d < Zd; ++d)
-          cj += (cs_xlogy(qloc[j * Zd + d], z[d]) + cs_xlogy(q2v[j * Zd + d], 1.0f - z[d])) + qls[j * Zd + d];
-      } else {
-        for (int d = 0; d < Zd; ++d) {
-          const float df = z[d] - qloc[j * Zd + d];
-          cj += -(df * df) * q2v[j * Zd + d] - qls[j * Zd + d] - CS_LOG_SQRT_2PI;
-        }
-      }
-      return cj;
-    };
-    // mixture components of this proposal: j = gm + mixG*cc, cc < mixc
-    const int gm = kp_s % a.mixG;
+    // deterministic-mixture density of the proposal: logsumexp over its components - log(count)
+    const float* cv = l_c + (e_l * S + s) * a.mixc;
     float ql;
     if (a.cfg.weighting == CS_W_SMIS) {
-      ql = comp(kp_s);
+      ql = cv[0];
     } else {
+      const int gm = kp_s - cs_div(kp_s, a.dmixG) * a.mixG;
       float m = -INFINITY, sum = 0.0f;
       int ncomp = 0;
-      if (a.mixc <= 8) {
-        // small mixtures: every component density is evaluated once and kept in registers
-        float cv[8];
-#pragma unroll
-        for (int cc = 0; cc < 8; ++cc) {
-          const int j = gm + a.mixG * cc;
-          const bool on = cc < a.mixc && j < Kp;  // j >= Kp: padded layout, this member does not exist
-          cv[cc] = on ? comp(j) : -INFINITY;
-          ncomp += on ? 1 : 0;
-          m = fmaxf(m, cv[cc]);
-        }
-        if (!(fabsf(m) < INFINITY)) m = 0.0f;
-#pragma unroll
-        for (int cc = 0; cc < 8; ++cc)
-          if (cc < ncomp) sum += expf(cv[cc] - m);
-      } else {
-        for (int cc = 0; cc < a.mixc; ++cc) {
-          const int j = gm + a.mixG * cc;
-          if (j >= Kp) break;
-          const float cj = comp(j);
-          m = fmaxf(m, cj);
-          ++ncomp;
-        }
-        if (!(fabsf(m) < INFINITY)) m = 0.0f;
-        for (int cc = 0; cc < ncomp; ++cc) {
-          const int j = gm + a.mixG * cc;
-          const float cj = comp(j);
-          sum += expf(cj - m);
-        }
+      for (int cc = 0; cc < a.mixc && gm + a.mixG * cc < Kp; ++cc) {
+        m = fmaxf(m, cv[cc]);
+        ++ncomp;
       }
+      if (!(fabsf(m) < INFINITY)) m = 0.0f;
+      for (int cc = 0; cc < ncomp; ++cc) sum += expf(cv[cc] - m);
       ql = logf(sum) + m - logf((float)ncomp);
     }
-    const int64_t rho = ((int64_t)i_s * B + b) * Kp + kp_s;
-    lw = a.b.gen_ll[rho] + pl - ql;
-    a.b.log_w[rho] = lw;
+    lw = gll + pl - ql;
+    a.b.log_w[rho_s] = lw;
   }
   const float tlw = (a.cfg.weight_alpha == 1.0f) ? lw : lw * a.cfg.weight_alpha;
+  CS_TICK();
 
   // ---- ESS / perplexity over all S proposals (vae_imputation.py:708-719) ----
   {
@@ -233,6 +321,7 @@ __global__ void __launch_bounds__(64) cs_lair_resample_kernel(const CsResampleAr
     }
   }
 
+  CS_TICK();
   // ---- resampling within groups ----
   const float nl = tlw - seg_lse(tlw, true);  // normalised log-weight (Categorical.logits)
   // ir returns the (transformed) log-weights themselves, in '(i k)' order (vae_imputation.py:479-480)
@@ -263,6 +352,7 @@ __global__ void __launch_bounds__(64) cs_lair_resample_kernel(const CsResampleAr
   const unsigned long long ex_mask = (S == 64 ? ~0ull : ((1ull << S) - 1ull)) << base;
 
   const int ndraw_sets = (a.b.latents_resampled != nullptr) ? 2 : 1;
+  CS_TICK();
   int* my_idx = l_idx + e_l * 2 * NS;
   for (int set = 0; set < ndraw_sets; ++set) {
     if (race) {
@@ -295,14 +385,21 @@ __global__ void __launch_bounds__(64) cs_lair_resample_kernel(const CsResampleAr
       float cn = cum / run;
       if (last_in_group) cn = 1.0f;
       const double* uin = set == 0 ? a.b.u_res : a.b.u_res2;
-      for (int g = 0; g < G; ++g) {
-        for (int t = 0; t < c; ++t) {
-          double u = 0.0;
-          if (act) {
-            if (uin) u = uin[(b * G + g) * c + t];
-            else u = cs_uniform64_elem(a.rng, set == 0 ? CS_STREAM_URES : CS_STREAM_URES2, a.rng.row_offset + b,
-                                       (uint32_t)(g * c + t));
-          }
+      // Draw dr = g*c + t of the example.  The example's S lanes fetch / generate S draws at a
+      // time (one counter-RNG block per lane instead of one per lane and draw), then the draws
+      // are broadcast one by one.
+      const int ND = G * c;
+      int g = 0, t = 0;
+      for (int d0 = 0; d0 < ND; d0 += S) {
+        double u_mine = 0.0;
+        if (act && d0 + s < ND) {
+          if (uin) u_mine = uin[b * ND + d0 + s];
+          else u_mine = cs_uniform64_elem(a.rng, set == 0 ? CS_STREAM_URES : CS_STREAM_URES2, a.rng.row_offset + b,
+                                          (uint32_t)(d0 + s));
+        }
+        const int nd = ND - d0 < S ? ND - d0 : S;
+        for (int jj = 0; jj < nd; ++jj) {
+          const double u = __shfl(u_mine, base + jj);
           const unsigned long long mask = __ballot(act && g_s == g && (double)cn < u);
           int li = __popcll(mask & ex_mask);
           // the group's first member records the draw; output slot t*G + g ('c b k d -> b (c k) d')
@@ -310,6 +407,7 @@ __global__ void __launch_bounds__(64) cs_lair_resample_kernel(const CsResampleAr
             if (li > gsize - 1) li = gsize - 1;
             my_idx[set * NS + t * G + g] = nth_member(li);
           }
+          if (++t == c) { t = 0; ++g; }
         }
       }
     } else {
@@ -336,8 +434,9 @@ __global__ void __launch_bounds__(64) cs_lair_resample_kernel(const CsResampleAr
     }
   }
   __syncthreads();
+  CS_TICK();
   for (int t = lane; t < ne * NS; t += 64) {
-    const int e = t / NS, n = t - e * NS;
+    const int e = cs_div(t, a.dNS), n = t - e * NS;
     a.b.idx[(b0 + e) * NS + n] = l_idx[e * 2 * NS + n];
     if (ndraw_sets == 2 && a.b.idx2) a.b.idx2[(b0 + e) * NS + n] = l_idx[e * 2 * NS + NS + n];
   }
@@ -345,9 +444,9 @@ __global__ void __launch_bounds__(64) cs_lair_resample_kernel(const CsResampleAr
   // ---- resampled latents (second, independent draw; vae_imputation.py:649-650) ----
   if (ndraw_sets == 2) {
     for (int t = lane; t < ne * NS * Zd; t += 64) {
-      const int en = t / Zd, d = t - en * Zd;
-      const int e = en / NS, n = en - e * NS;
-      a.b.latents_resampled[b0 * NS * Zd + t] = l_z[(e * S + l_idx[e * 2 * NS + NS + n]) * (Zd + 1) + d];
+      const int en = cs_div(t, a.dZd), d = t - en * Zd;
+      const int e = cs_div(en, a.dNS), n = en - e * NS;
+      a.b.latents_resampled[b0 * NS * Zd + t] = l_z[(e * S + l_idx[e * 2 * NS + NS + n]) * ZS + d];
     }
   }
 
@@ -355,25 +454,37 @@ __global__ void __launch_bounds__(64) cs_lair_resample_kernel(const CsResampleAr
   // work item = 4 consecutive dimensions of one chain (one Philox block = 4 normals)
   // Only the first Kimp chains are imputed (the historical ones beyond them only propose); the new
   // values go to X_out[B,Kimp,D] when given, else in place.
+  CS_TICK();
   const int DQ = (D + 3) >> 2;
   const bool bern = a.cfg.gen_dist == CS_DIST_BERN;
   const bool clip = a.b.clip_min || a.b.clip_max;
   const int Kimp = a.Kimp;
   for (int t = lane; t < ne * Kimp * DQ; t += 64) {
-    const int en = t / DQ, dq = t - en * DQ;
-    const int e = en / Kimp, n = en - e * Kimp;
+    const int en = cs_div(t, a.dDQ), dq = t - en * DQ;
+    const int e = cs_div(en, a.dKimp), n = en - e * Kimp;
     const int64_t be = b0 + e;
     const int src = l_idx[e * 2 * NS + n];
-    const int i = src / Kp, kp = src - i * Kp;
+    const int i = cs_div(src, a.dKp), kp = src - i * Kp;
     const int64_t rho = ((int64_t)i * B + be) * Kp + kp;
     const float* xr = a.b.X + (be * K + n) * D;
     float* xw = a.b.X_out ? a.b.X_out + (be * Kimp + n) * D : a.b.X + (be * K + n) * D;
     const uint8_t* mr = a.b.M + be * D;
-    float dr[4];
-    if (a.b.eps_x) {
+    // every input of the item is requested before anything is computed or stored: X is updated in
+    // place, so a load placed after a store could not be moved ahead of it, and the item would pay
+    // one memory round trip per dimension
+    const float* gr = a.b.gen + rho * (bern ? 1 : 2) * D;
+    float g0[4], g1[4], xo[4], mk[4], dr[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) dr[r] = (4 * dq + r < D) ? a.b.eps_x[(be * Kimp + n) * D + 4 * dq + r] : 0.0f;
-    } else {
+    for (int r = 0; r < 4; ++r) {
+      const int d = 4 * dq + r;
+      const bool in = d < D;
+      g0[r] = in ? gr[d] : 0.0f;
+      g1[r] = (in && !bern) ? gr[D + d] : 0.0f;
+      xo[r] = in ? xr[d] : 0.0f;
+      mk[r] = in ? (float)mr[d] : 1.0f;
+      dr[r] = (in && a.b.eps_x) ? a.b.eps_x[(be * Kimp + n) * D + d] : 0.0f;
+    }
+    if (!a.b.eps_x) {
       uint32_t x[4];
       cs_philox_block(a.rng, CS_STREAM_X, (a.rng.row_offset + be) * Kimp + n, (uint32_t)dq, x);
       if (bern) {
@@ -384,23 +495,33 @@ __global__ void __launch_bounds__(64) cs_lair_resample_kernel(const CsResampleAr
         dr[0] = nn.x; dr[1] = nn.y; dr[2] = nn.z; dr[3] = nn.w;
       }
     }
+    float xn[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int d = 4 * dq + r;
+      float xm;
+      if (bern) xm = (dr[r] < cs_sigmoid(g0[r])) ? 1.0f : 0.0f;
+      else xm = g0[r] + g1[r] * dr[r];
+      xn[r] = xo[r] * mk[r] + xm * (1.0f - mk[r]);
       if (d < D) {
-        float xm;
-        if (bern) xm = (dr[r] < cs_sigmoid(a.b.gen[rho * D + d])) ? 1.0f : 0.0f;
-        else xm = a.b.gen[rho * 2 * D + d] + a.b.gen[rho * 2 * D + D + d] * dr[r];
-        const float xo = xr[d];
-        const float m = (float)mr[d];
-        float xn = xo * m + xm * (1.0f - m);
-        if (a.b.clip_min) xn = (xn != xn) ? xn : fmaxf(xn, a.b.clip_min[d]);
-        if (a.b.clip_max) xn = (xn != xn) ? xn : fminf(xn, a.b.clip_max[d]);
-        if (clip && !(fabsf(xn) < INFINITY)) xn = xo;
-        xw[d] = xn;
+        if (a.b.clip_min) xn[r] = (xn[r] != xn[r]) ? xn[r] : fmaxf(xn[r], a.b.clip_min[d]);
+        if (a.b.clip_max) xn[r] = (xn[r] != xn[r]) ? xn[r] : fminf(xn[r], a.b.clip_max[d]);
+        if (clip && !(fabsf(xn[r]) < INFINITY)) xn[r] = xo[r];
       }
     }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (4 * dq + r < D) xw[4 * dq + r] = xn[r];
   }
+#ifdef CS_RS_PROFILE
+  CS_TICK();
+  __syncthreads();
+  if (lane == 0 && ne >= 3)
+    for (int i = 0; i + 1 < tn; ++i) {
+      float* dst = i < 3 ? a.b.ess : (i < 6 ? a.b.tess : a.b.perplexity);
+      dst[b0 + i % 3] = (float)(T[i + 1] - T[i]);
+    }
+#endif
 }
 
 // ----------------------------------------------------------------------------------------
@@ -598,15 +719,30 @@ extern "C" int cs_lair_resample_impute(const cs_lair_cfg* c, const cs_lair_bufs*
   CS_REQUIRE(c->method == CS_RM_MULTINOMIAL || c->method == CS_RM_SYSTEMATIC, "bad resampling method");
   if (c->B == 0) return CS_OK;
   a.NS = a.G * a.c;
-  const int per_example = 3 * a.Kp * c->Zd + a.S * (c->Zd + 1) + 2 * a.NS;  // floats of LDS
+  // 16-byte staging / density loops when the rows allow it
+  const bool vec = (c->Zd % 4 == 0) && (((uintptr_t)b->q | (uintptr_t)b->Z) & 15u) == 0;
+  // staged rows padded so that the examples (q) and proposals (Z) of a wavefront start in different banks
+  const int qn = a.Kp * c->Zd;
+  a.q_stride = vec ? (((qn >> 2) | 1) << 2) : (qn | 1);
+  a.z_stride = vec ? c->Zd + 4 : c->Zd + 1;
+  const int per_example = 3 * a.q_stride + a.S * a.z_stride + 2 * a.NS + a.S * a.mixc;  // floats of LDS
   a.E = 64 / a.S;
   // more examples per wavefront fill more lanes, but the LDS working set limits how many
   // wavefronts are resident; ~12 KB per wavefront measured best (MiniBooNE shape)
   while (a.E > 1 && (size_t)a.E * per_example * 4 > 12 * 1024) --a.E;
   CS_REQUIRE((size_t)a.E * per_example * 4 <= 64 * 1024, "proposal set too large for the LDS working set");
   a.lds_per_wave = a.E * per_example;
+  const int DQ = (c->D + 3) >> 2;
+  // ranges of the multiply-high divisions: index * divisor < 2^32
+  CS_REQUIRE((uint64_t)64 * c->Zd * c->Zd < (1ull << 32) && (uint64_t)64 * DQ * DQ < (1ull << 32), "D or Zd too large");
+  a.dZd = cs_mkdiv(c->Zd); a.dZq = cs_mkdiv(vec ? c->Zd >> 2 : 1); a.dS = cs_mkdiv(a.S); a.dKp = cs_mkdiv(a.Kp);
+  a.dNS = cs_mkdiv(a.NS); a.dDQ = cs_mkdiv(DQ); a.dKimp = cs_mkdiv(a.Kimp);
+  a.dMC = cs_mkdiv(a.mixc); a.dmixG = cs_mkdiv(a.mixG);
   const unsigned grid = (unsigned)((c->B + a.E - 1) / a.E);
-  hipLaunchKernelGGL(cs_lair_resample_kernel, dim3(grid), dim3(64), (size_t)a.lds_per_wave * 4, (hipStream_t)stream, a);
+  if (vec)
+    hipLaunchKernelGGL(cs_lair_resample_kernel<true>, dim3(grid), dim3(64), (size_t)a.lds_per_wave * 4, (hipStream_t)stream, a);
+  else
+    hipLaunchKernelGGL(cs_lair_resample_kernel<false>, dim3(grid), dim3(64), (size_t)a.lds_per_wave * 4, (hipStream_t)stream, a);
   CS_HIP(hipGetLastError());
   return CS_OK;
 }

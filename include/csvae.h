@@ -358,6 +358,19 @@ int cs_rng_normal(const cs_rng* rng, uint32_t stream_id, int64_t rows, int32_t c
 int cs_rng_uniform(const cs_rng* rng, uint32_t stream_id, int64_t rows, int32_t cols, float* out, void* stream);
 int cs_rng_uniform64(const cs_rng* rng, uint32_t stream_id, int64_t rows, int32_t cols, double* out, void* stream);
 
+/* Arithmetic of the matrix products of the fused residual-MLP kernel (no counterpart in the
+ * reference, whose torch.nn.Linear layers compute in float32):
+ *   CS_ARITH_F32     exact float32 matrix instructions (default);
+ *   CS_ARITH_BF16X3  every float32 operand is split exactly into three bfloat16 terms and a product
+ *                    is accumulated in float32 from the six leading term products; the neglected
+ *                    terms are below 2^-23 of |a||b|, the size of one float32 rounding, so results
+ *                    are float32-equivalent (same tolerances), not bit-identical to CS_ARITH_F32.
+ * The setting is process-wide and applies to launches made after the call; the environment variable
+ * CSVAE_MLP_ARITH (f32 | bf16x3) gives the initial value.  Layer-program networks are not affected. */
+enum { CS_ARITH_F32 = 0, CS_ARITH_BF16X3 = 1 };
+int cs_set_mlp_arith(int arith);
+int cs_get_mlp_arith(void);
+
 /* Profiling hook (no counterpart in the reference): when buf != NULL every fused-MLP launch
  * writes 16 int64 per 16-row tile into buf (device memory, 16*ceil(rows/16) int64): clock stamps in
  * slots 0..14, (XCC_ID << 32 | HW_ID) of the wavefront in slot 15. */

@@ -141,6 +141,7 @@ def lib():
     L.cs_decode_params.argtypes = [vp, vp, i64, i32, vp, vp]
     L.cs_gen_loglik_rows.argtypes = [vp, i32, vp, vp, i64, i32, i32, vp, vp]
     L.cs_debug_set_workspace_budget.argtypes = [i64]
+    L.cs_set_mlp_arith.argtypes = [i32]
     L.cs_imputation_errors.argtypes = [vp, vp, vp, i64, i32, i32, vp, vp, vp]
     L.cs_latent_wasserstein.argtypes = [vp, vp, i64, i32, i32, vp, vp]
     L.cs_sample_impute.argtypes = [vp, i32, vp, C.POINTER(cs_rng), u32, vp, vp, i64, i32, i32, vp, vp, i32, vp]
@@ -148,6 +149,23 @@ def lib():
         getattr(L, fn).argtypes = [C.POINTER(cs_rng), u32, i64, i32, vp, vp]
     _lib = L
     return L
+
+
+CS_ARITH = {"f32": 0, "bf16x3": 1}
+
+
+def set_mlp_arith(name):
+    """Arithmetic of the fused-MLP matrix products: 'f32' (exact float32 matrix instructions) or 'bf16x3'
+    (float32 operands split exactly into three bfloat16 terms, six term products accumulated in float32:
+    float32-equivalent results at 6/16 of the matrix time).  Process-wide; returns the previous setting."""
+    prev = get_mlp_arith()
+    check(lib().cs_set_mlp_arith(CS_ARITH[name]))
+    return prev
+
+
+def get_mlp_arith():
+    v = lib().cs_get_mlp_arith()
+    return next(k for k, c in CS_ARITH.items() if c == v)
 
 
 def check(rc):

@@ -16,6 +16,11 @@ struct CsMlpDev {
   int split;
   int bias_stride;
   const void* prog;      // host pointer to a CsProgram when the network is a layer program, else null
+  // split-bf16 variant (cs_mlp_split_kernel.inc): weights as three bf16 terms in 32-row tile order
+  const f32x4* wstream3; // packed bf16x8 fragments (16 bytes each)
+  const float* bias3;    // [2*nb+2][bias_stride3], final layer in 32-row tile order
+  int nto3;              // output tiles of 32
+  int bias_stride3;
 };
 
 struct CsProgram;
@@ -24,6 +29,8 @@ struct cs_mlp {
   CsMlpDev dev;
   void* d_w;
   void* d_b;
+  void* d_w3;
+  void* d_b3;
   int device;
   CsProgram* prog;  // layer-program networks (cs_net_create); null for the fused MLP
 };
@@ -61,3 +68,5 @@ struct CsMlpArgs {
 };
 
 int cs_mlp_launch(const CsMlpArgs& a, hipStream_t stream);
+// CS_ARITH_* in force for fused-MLP launches (cs_set_mlp_arith, or CSVAE_MLP_ARITH at first use)
+int cs_mlp_arith();

@@ -19,6 +19,27 @@
 int cs_mlp_launch_h64(const CsMlpArgs& a, hipStream_t stream);
 int cs_mlp_launch_h128(const CsMlpArgs& a, hipStream_t stream);
 int cs_mlp_launch_h256(const CsMlpArgs& a, hipStream_t stream);
+int cs_mlp_split_launch_h64(const CsMlpArgs& a, hipStream_t stream);
+int cs_mlp_split_launch_h128(const CsMlpArgs& a, hipStream_t stream);
+int cs_mlp_split_launch_h256(const CsMlpArgs& a, hipStream_t stream);
+
+// Arithmetic of the fused-MLP matrix products: exact f32 matrix instructions, or the f32-equivalent
+// 3-way bf16 split (6 bf16 matrix instructions per product, cs_mlp_split_kernel.inc).  -1 = not
+// decided yet: the environment variable CSVAE_MLP_ARITH (f32 | bf16x3) is read at first use.
+static int g_arith = -1;
+int cs_mlp_arith() {
+  if (g_arith < 0) {
+    const char* e = std::getenv("CSVAE_MLP_ARITH");
+    g_arith = (e && std::strcmp(e, "bf16x3") == 0) ? CS_ARITH_BF16X3 : CS_ARITH_F32;
+  }
+  return g_arith;
+}
+extern "C" int cs_set_mlp_arith(int arith) {
+  CS_REQUIRE(arith == CS_ARITH_F32 || arith == CS_ARITH_BF16X3, "unknown arithmetic");
+  g_arith = arith;
+  return CS_OK;
+}
+extern "C" int cs_get_mlp_arith(void) { return cs_mlp_arith(); }
 
 static long long* g_trace = nullptr;
 // Profiling hook: when set, every fused-MLP launch writes 16 int64 per wavefront (16-row tile)
@@ -46,6 +67,13 @@ int cs_mlp_launch(const CsMlpArgs& a_in, hipStream_t stream) {
   if (a.mode == CS_MLP_ENC) CS_REQUIRE(a.net.split == 2, "encoder output must be (loc | scale)");
   if (a.mode == CS_MLP_DEC && a.gen_dist != CS_DIST_BERN)
     CS_REQUIRE(a.net.split == 2, "generator output must be (loc | scale)");
+  if (cs_mlp_arith() == CS_ARITH_BF16X3) {
+    switch (a.net.nt) {
+      case 4: return cs_mlp_split_launch_h64(a, stream);
+      case 8: return cs_mlp_split_launch_h128(a, stream);
+      case 16: return cs_mlp_split_launch_h256(a, stream);
+    }
+  }
   switch (a.net.nt) {
     case 4: return cs_mlp_launch_h64(a, stream);
     case 8: return cs_mlp_launch_h128(a, stream);
@@ -74,6 +102,43 @@ void pack_layer(std::vector<float>& s, const float* W, int k_real, int kt_count,
             s.push_back((n >= 0 && k < k_real) ? W[(size_t)n * k_real + k] : 0.0f);
           }
         }
+}
+
+// round-to-nearest-even bf16 of a finite float, as the 16 high bits
+uint16_t bf16_rne(float f) {
+  uint32_t u;
+  std::memcpy(&u, &f, 4);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+float bf16_val(uint16_t h) {
+  const uint32_t u = (uint32_t)h << 16;
+  float f;
+  std::memcpy(&f, &u, 4);
+  return f;
+}
+// Split-bf16 operand stream of one layer: per 32-wide k-tile, per k-step of 16, per 32-row output
+// tile, per term p of the 3-way split, per lane (m = lane&31, h = lane>>5), the 8 columns
+// k = 32kt + 16ks + 8(j>>2) + 4h + (j&3) of row tile_row(t, m) (-1 = padding).
+template <class RowFn>
+void pack_layer3(std::vector<uint16_t>& s, const float* W, int k_real, int kt_count, int ntiles, RowFn tile_row) {
+  for (int kt = 0; kt < kt_count; ++kt)
+    for (int ks = 0; ks < 2; ++ks)
+      for (int t = 0; t < ntiles; ++t)
+        for (int p = 0; p < 3; ++p)
+          for (int lane = 0; lane < 64; ++lane) {
+            const int m = lane & 31, h = lane >> 5;
+            const int n = tile_row(t, m);
+            for (int j = 0; j < 8; ++j) {
+              const int k = 32 * kt + 16 * ks + 8 * (j >> 2) + 4 * h + (j & 3);
+              const float v = (n >= 0 && k < k_real) ? W[(size_t)n * k_real + k] : 0.0f;
+              const uint16_t t0 = bf16_rne(v);
+              const float r1 = v - bf16_val(t0);
+              const uint16_t t1 = bf16_rne(r1);
+              const uint16_t t2 = bf16_rne(r1 - bf16_val(t1));
+              s.push_back(p == 0 ? t0 : (p == 1 ? t1 : t2));
+            }
+          }
 }
 }  // namespace
 
@@ -121,19 +186,58 @@ extern "C" int cs_mlp_create(const cs_mlp_desc* d, const float* W0, const float*
       if (n >= 0) bias[(size_t)(nl - 1) * bst + 16 * t + i] = bf[n];
     }
 
+  // split-bf16 variant: 32-row tiles; a (loc | scale) output tile holds 16 loc rows then the 16 scale rows
+  // of the same feature indices
+  const int NT3 = H / 32;
+  const int nto3 = d->out_split == 2 ? (out_half + 15) / 16 : (d->out_dim + 31) / 32;
+  const int bst3 = 32 * (NT3 > nto3 ? NT3 : nto3);
+  std::vector<uint16_t> s3;
+  auto hid_row3 = [&](int t, int mrow) { return 32 * t + mrow; };
+  auto out_row3 = [&](int t, int mrow) {
+    if (d->out_split == 2) {
+      const int w = 16 * t + (mrow & 15);
+      return w < out_half ? (mrow >> 4) * out_half + w : -1;
+    }
+    const int n = 32 * t + mrow;
+    return n < d->out_dim ? n : -1;
+  };
+  pack_layer3(s3, W0, d->in_dim, nkt0, NT3, hid_row3);
+  for (int b = 0; b < nb; ++b)
+    for (int l = 0; l < 2; ++l) pack_layer3(s3, Wblk + ((size_t)b * 2 + l) * H * H, H, NKT, NT3, hid_row3);
+  pack_layer3(s3, Wf, H, NKT, nto3, out_row3);
+  s3.resize(s3.size() + ((size_t)2 * (NT3 > nto3 ? NT3 : nto3) * 3 * 64 + 256) * 8, 0);  // the last prefetch reads one (rounded) slot past the end
+  std::vector<float> bias3((size_t)nl * bst3, 0.0f);
+  for (int i = 0; i < H; ++i) bias3[i] = b0[i];
+  for (int b = 0; b < nb; ++b)
+    for (int l = 0; l < 2; ++l)
+      for (int i = 0; i < H; ++i) bias3[(size_t)(1 + 2 * b + l) * bst3 + i] = bblk[((size_t)b * 2 + l) * H + i];
+  for (int t = 0; t < nto3; ++t)
+    for (int i = 0; i < 32; ++i) {
+      const int n = out_row3(t, i);
+      if (n >= 0) bias3[(size_t)(nl - 1) * bst3 + 32 * t + i] = bf[n];
+    }
+
   cs_mlp* m = new cs_mlp();
   m->desc = *d;
   m->d_w = nullptr;
   m->d_b = nullptr;
+  m->d_w3 = nullptr;
+  m->d_b3 = nullptr;
   m->prog = nullptr;
   hipError_t e = hipGetDevice(&m->device);
   if (e == hipSuccess) e = hipMalloc(&m->d_w, s.size() * sizeof(float));
   if (e == hipSuccess) e = hipMalloc(&m->d_b, bias.size() * sizeof(float));
   if (e == hipSuccess) e = hipMemcpy(m->d_w, s.data(), s.size() * sizeof(float), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(m->d_b, bias.data(), bias.size() * sizeof(float), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMalloc(&m->d_w3, s3.size() * sizeof(uint16_t));
+  if (e == hipSuccess) e = hipMalloc(&m->d_b3, bias3.size() * sizeof(float));
+  if (e == hipSuccess) e = hipMemcpy(m->d_w3, s3.data(), s3.size() * sizeof(uint16_t), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(m->d_b3, bias3.data(), bias3.size() * sizeof(float), hipMemcpyHostToDevice);
   if (e != hipSuccess) {
     if (m->d_w) (void)hipFree(m->d_w);
     if (m->d_b) (void)hipFree(m->d_b);
+    if (m->d_w3) (void)hipFree(m->d_w3);
+    if (m->d_b3) (void)hipFree(m->d_b3);
     delete m;
     return cs_fail(CS_EHIP, std::string("cs_mlp_create: ") + hipGetErrorString(e));
   }
@@ -150,6 +254,10 @@ extern "C" int cs_mlp_create(const cs_mlp_desc* d, const float* W0, const float*
   m->dev.split = d->out_split;
   m->dev.bias_stride = bst;
   m->dev.prog = nullptr;
+  m->dev.wstream3 = (const f32x4*)m->d_w3;
+  m->dev.bias3 = (const float*)m->d_b3;
+  m->dev.nto3 = nto3;
+  m->dev.bias_stride3 = bst3;
   *out = m;
   return CS_OK;
 }
@@ -159,6 +267,8 @@ extern "C" int cs_mlp_destroy(cs_mlp_t* m) {
   cs_prog_destroy(m->prog);
   if (m->d_w) (void)hipFree(m->d_w);
   if (m->d_b) (void)hipFree(m->d_b);
+  if (m->d_w3) (void)hipFree(m->d_w3);
+  if (m->d_b3) (void)hipFree(m->d_b3);
   delete m;
   return CS_OK;
 }

@@ -724,7 +724,7 @@ extern "C" int cs_net_create(const cs_layer_desc* layers, int32_t n_layers, cons
   std::memset(&m->desc, 0, sizeof(m->desc));
   std::memset(&m->dev, 0, sizeof(m->dev));
   m->desc.in_dim = in_dim; m->desc.out_dim = out_dim; m->desc.out_split = out_split;
-  m->d_w = nullptr; m->d_b = nullptr;
+  m->d_w = nullptr; m->d_b = nullptr; m->d_w3 = nullptr; m->d_b3 = nullptr;
   m->device = p->device;
   m->prog = p;
   m->dev.in_dim = in_dim; m->dev.out_dim = out_dim; m->dev.out_half = out_dim / out_split; m->dev.split = out_split;

@@ -12,8 +12,11 @@ the loop.  The metric is conditional samples/s = (examples x K x steps) / second
 over ranks (weak scaling: the per-GPU batch is fixed).
 
 Prints ONE JSON line on rank 0 with the roofline of the dominant kernel (the fused encoder
-MLP, exact-f32 MFMA) and a CPU baseline (the torch-CPU oracle of this repository on a bounded
-sample of the same workload).
+MLP on the matrix cores) and a CPU baseline (the torch-CPU oracle of this repository on a bounded
+sample of the same workload).  The MLP kernel's default arithmetic builds each float32 product from
+the bf16 terms of an exact 3-way split of both operands (float32-equivalent results); `--arith f32`
+selects the exact-float32 matrix instructions, and at one GPU the line also carries that
+arithmetic's throughput ("exact_f32").
 """
 import argparse
 import ctypes as C
@@ -34,6 +37,10 @@ WORKLOADS = {
     "gas": dict(D=8, Zd=16, H=256, nbe=2, nbd=2, K=16, R=1),
 }
 F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X exact-f32 matrix peak
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X dense bf16 matrix peak
+# The default arithmetic of the fused MLP kernel forms every float32 product from 6 bf16 term products
+# (exact 3-way split of both operands, float32 accumulation): its ceiling in algorithmic (float32) FLOP/s
+SPLIT_PEAK_TFLOPS = BF16_MFMA_PEAK_TFLOPS / 6.0
 
 
 def resfc_flops(i, H, nb, o):
@@ -48,6 +55,9 @@ def main():
     ap.add_argument("--workload", default="miniboone", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=65536, help="examples per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--arith", default=None, choices=["bf16x3", "f32"],
+                    help="arithmetic of the fused MLP kernel (default: the library's, bf16x3 = exact 3-way bf16 split of "
+                         "the float32 operands, float32 accumulation, float32-equivalent results)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -66,6 +76,9 @@ def main():
     from vae_conditional_sampling_amd.models import VAE, ResidualFCNetwork
     from vae_conditional_sampling_amd.sampling import engine
 
+    if args.arith:
+        _lib.set_mlp_arith(args.arith)
+    arith = _lib.get_mlp_arith()
     w = WORKLOADS[args.workload]
     D, Zd, H, K, R = w["D"], w["Zd"], w["H"], w["K"], w["R"]
     B = args.batch
@@ -148,6 +161,21 @@ def main():
             dist.destroy_process_group()
         return
 
+    # the same K steps on the exact-float32 matrix instructions, for comparison (outside the timed region)
+    exact = None
+    if arith != "f32" and world == 1:
+        _lib.set_mlp_arith("f32")
+        for t in range(args.warmup):
+            step(t)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for t in range(args.steps):
+            step(args.warmup + t)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t1
+        _lib.set_mlp_arith(arith)
+        exact = {"value": B * K * args.steps / el, "ms_per_step": el / args.steps * 1e3, "unit": "samples/s"}
+
     ms = lambda a, b: sum(e[a].elapsed_time(e[b]) for e in evs) / len(evs)
     enc_ms, dec_ms, res_ms = ms(0, 1), ms(1, 2), ms(2, 3)
     f_enc = resfc_flops(D, H, w["nbe"], 2 * Zd)
@@ -157,6 +185,8 @@ def main():
     enc_tf = enc_flops / (enc_ms * 1e-3) / 1e12
     dec_tf = dec_flops / (dec_ms * 1e-3) / 1e12
     value = world * B * K * args.steps / elapsed
+    split = arith == "bf16x3"
+    peak = SPLIT_PEAK_TFLOPS if split else F32_MFMA_PEAK_TFLOPS
     Kp = K + R
     res_bytes = (Kp * 2 * Zd * 4 + Kp * Zd * 4 + Kp * 4 + K * (2 * D * 4 + D * 4) + D) + (K * D * 4 + 2 * Kp * 4 + Kp * 8 + 12)
 
@@ -175,21 +205,27 @@ def main():
         "metric": "conditional samples/sec (N x K chains) for LAIR",
         "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "vs_baseline": None, "dtype": "f32 as 3 bf16 terms per operand, f32 accumulation" if split else "f32", "data": "synthetic",
         "config": {"workload": f"uci_{args.workload} MLP-VAE LAIR (dmis/gr/multinomial), D={D} Zd={Zd} H={H} "
                                f"enc_blocks={w['nbe']} dec_blocks={w['nbd']} K={K} R={R} I=1",
                    "examples_per_gpu": B, "chains_per_gpu": B * K, "sharding": f"examples x{world}, no collective in loop"},
-        "roofline": {"bound": "mfma", "kernel": "cs_mlp_kernel (encoder launch)", "achieved": enc_tf,
-                     "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": enc_tf / F32_MFMA_PEAK_TFLOPS,
-                     "traffic": traffic, "flops_per_launch": enc_flops, "avg_launch_ms": enc_ms},
+        "roofline": {"bound": "mfma", "kernel": ("cs_mlp_split_kernel" if split else "cs_mlp_kernel") + " (encoder launch)",
+                     "achieved": enc_tf, "peak": peak, "unit": "TFLOP/s", "frac": enc_tf / peak,
+                     "traffic": traffic, "flops_per_launch": enc_flops, "avg_launch_ms": enc_ms,
+                     "note": ("algorithmic float32 FLOPs; each is executed as 6 bf16 matrix FLOPs, so peak = dense bf16 "
+                              "peak 2500 / 6 and the executed bf16 rate is 6 x achieved") if split else
+                             "algorithmic float32 FLOPs on the exact-f32 matrix instructions"},
         "kernels": {"encoder_ms": enc_ms, "decoder_ms": dec_ms, "resample_impute_ms": res_ms,
                     # HBM-bound stage: algorithmic bytes per example (q, Z, gen_ll, the K chosen generator rows,
                     # X and M read; X, log-weights, normalised weights, indices, statistics written)
                     "resample_impute_GBps": B * res_bytes / (res_ms * 1e-3) / 1e9, "resample_impute_bytes_per_example": res_bytes,
-                    "decoder_tflops": dec_tf, "decoder_frac": dec_tf / F32_MFMA_PEAK_TFLOPS,
+                    "decoder_tflops": dec_tf, "decoder_frac": dec_tf / peak,
                     "step_flops": enc_flops + dec_flops,
-                    "step_mfma_frac": (enc_flops + dec_flops) / ((enc_ms + dec_ms + res_ms) * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS},
+                    "step_mfma_frac": (enc_flops + dec_flops) / ((enc_ms + dec_ms + res_ms) * 1e-3) / 1e12 / peak,
+                    "mlp_arith": arith},
     }
+    if exact is not None:
+        out["exact_f32"] = exact
 
     if not args.no_cpu_baseline and world == 1:
         from oracle import cs_oracle as O  # the checker, used here only as the timed CPU baseline

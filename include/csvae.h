@@ -360,13 +360,16 @@ int cs_rng_uniform64(const cs_rng* rng, uint32_t stream_id, int64_t rows, int32_
 
 /* Arithmetic of the matrix products of the fused residual-MLP kernel (no counterpart in the
  * reference, whose torch.nn.Linear layers compute in float32):
- *   CS_ARITH_F32     exact float32 matrix instructions (default);
- *   CS_ARITH_BF16X3  every float32 operand is split exactly into three bfloat16 terms and a product
- *                    is accumulated in float32 from the six leading term products; the neglected
- *                    terms are below 2^-23 of |a||b|, the size of one float32 rounding, so results
- *                    are float32-equivalent (same tolerances), not bit-identical to CS_ARITH_F32.
+ *   CS_ARITH_BF16X3  (default) every float32 operand is split exactly into three bfloat16 terms
+ *                    (8 + 8 + 8 significand bits) and a product is accumulated in float32 from the
+ *                    six leading term products; the neglected terms are below 2^-23 of |a||b|, the
+ *                    size of one float32 rounding.  Results are float32-equivalent: against a float64
+ *                    evaluation the error equals that of the exact-float32 kernel (tests/
+ *                    test_gpu_split_arith.py), they are not bit-identical to it.  Operands that are
+ *                    infinite or within a factor 2^-8 of FLT_MAX give NaN where float32 gives +-inf.
+ *   CS_ARITH_F32     exact float32 matrix instructions (1.66x the time).
  * The setting is process-wide and applies to launches made after the call; the environment variable
- * CSVAE_MLP_ARITH (f32 | bf16x3) gives the initial value.  Layer-program networks are not affected. */
+ * CSVAE_MLP_ARITH (bf16x3 | f32) gives the initial value.  Layer-program networks are not affected. */
 enum { CS_ARITH_F32 = 0, CS_ARITH_BF16X3 = 1 };
 int cs_set_mlp_arith(int arith);
 int cs_get_mlp_arith(void);

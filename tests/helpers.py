@@ -103,3 +103,17 @@ def make_conv_model(net, enc_w, dec_w, latent_dist, gen_dist, device="cuda"):
     enc.load_state_dict(OC.state_dict_of(enc_w), strict=True)
     dec.load_state_dict(OC.state_dict_of(dec_w), strict=True)
     return VAE(dec, gen_dist, enc, latent_dist).to(device)
+
+
+def arith_fixture():
+    """Autouse fixture for the MLP parity modules: every test runs once per arithmetic of the fused MLP
+    kernel (exact float32 matrix instructions, and the float32-equivalent 3-way bfloat16 split)."""
+    import pytest
+
+    @pytest.fixture(autouse=True, params=["f32", "bf16x3"])
+    def mlp_arith(request):
+        from vae_conditional_sampling_amd import _lib
+        prev = _lib.set_mlp_arith(request.param)
+        yield request.param
+        _lib.set_mlp_arith(prev)
+    return mlp_arith

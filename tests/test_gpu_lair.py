@@ -17,6 +17,9 @@ from tests.helpers import (RTOL, assert_close, load_golden, make_model, seeded_i
 
 pytestmark = pytest.mark.gpu
 
+from tests.helpers import arith_fixture  # noqa: E402
+mlp_arith = arith_fixture()
+
 LAIR_CASES = ["lair_gr_mult_small", "lair_gr_mult_i2_lat", "lair_gr_mult_noreplenish", "lair_gr_syst",
               "lair_glr_groups", "lair_miniboone_shape", "lair_tempered_annealed", "lair_annealed_025_normal",
               "lair_tempered", "lair_lr_mult", "lair_lr_syst", "lair_ir_mult", "lair_ir_mult_i6", "lair_ir_syst",

@@ -13,6 +13,9 @@ from tests.helpers import assert_close, load_golden, make_model, weights_from_fi
 
 pytestmark = pytest.mark.gpu
 
+from tests.helpers import arith_fixture  # noqa: E402
+mlp_arith = arith_fixture()
+
 BASE_KW = dict(store_last_n_iterations=-1, store_every_n_iterations=1, imputation_metric_quantiles=[],
                compute_f1_metric=False, compute_inv_f1_metric=False, compute_bin_accuracy_metric=False,
                compute_rmse_metric=False, compute_ssim_metric=False, compute_latent_wass_metric=False,

@@ -23,14 +23,15 @@ int cs_mlp_split_launch_h64(const CsMlpArgs& a, hipStream_t stream);
 int cs_mlp_split_launch_h128(const CsMlpArgs& a, hipStream_t stream);
 int cs_mlp_split_launch_h256(const CsMlpArgs& a, hipStream_t stream);
 
-// Arithmetic of the fused-MLP matrix products: exact f32 matrix instructions, or the f32-equivalent
-// 3-way bf16 split (6 bf16 matrix instructions per product, cs_mlp_split_kernel.inc).  -1 = not
-// decided yet: the environment variable CSVAE_MLP_ARITH (f32 | bf16x3) is read at first use.
+// Arithmetic of the fused-MLP matrix products: the f32-equivalent 3-way bf16 split (6 bf16 matrix
+// instructions per product, cs_mlp_split_kernel.inc; the default: measured as accurate against a
+// float64 evaluation as the exact-f32 kernel, at 0.6 of its time), or exact f32 matrix instructions.
+// -1 = not decided yet: the environment variable CSVAE_MLP_ARITH (f32 | bf16x3) is read at first use.
 static int g_arith = -1;
 int cs_mlp_arith() {
   if (g_arith < 0) {
     const char* e = std::getenv("CSVAE_MLP_ARITH");
-    g_arith = (e && std::strcmp(e, "bf16x3") == 0) ? CS_ARITH_BF16X3 : CS_ARITH_F32;
+    g_arith = (e && std::strcmp(e, "f32") == 0) ? CS_ARITH_F32 : CS_ARITH_BF16X3;
   }
   return g_arith;
 }
@@ -56,8 +57,10 @@ int cs_mlp_launch(const CsMlpArgs& a_in, hipStream_t stream) {
   a.dbg = g_trace;
   if (a.rows <= 0) return CS_OK;
   if (a.net.prog) return cs_prog_launch(a, stream);
-  if (a.mode == CS_MLP_DEC && a.in == nullptr && a.latent_dist == CS_DIST_BETA) {
-    // Beta proposals are drawn by a kernel of their own; the fused kernel then reads Z as its input
+  if (a.mode == CS_MLP_DEC && a.in == nullptr && (a.latent_dist == CS_DIST_BETA || cs_mlp_arith() == CS_ARITH_BF16X3)) {
+    // Beta proposals are drawn by a kernel of their own; the fused kernel then reads Z as its input.
+    // The split-bf16 kernel runs one wavefront per SIMD, so nothing would cover the counter-RNG work of
+    // its prologue: there too the proposals are drawn by the full-occupancy kernel first.
     if (int rc = cs_dec_stage_launch(a, 0, a.rows, stream)) return rc;
     a.in = a.Z;
     a.in_stride = a.Zd;
@@ -206,7 +209,7 @@ extern "C" int cs_mlp_create(const cs_mlp_desc* d, const float* W0, const float*
     for (int l = 0; l < 2; ++l) pack_layer3(s3, Wblk + ((size_t)b * 2 + l) * H * H, H, NKT, NT3, hid_row3);
   pack_layer3(s3, Wf, H, NKT, nto3, out_row3);
   s3.resize(s3.size() + ((size_t)2 * (NT3 > nto3 ? NT3 : nto3) * 3 * 64 + 256) * 8, 0);  // the last prefetch reads one (rounded) slot past the end
-  std::vector<float> bias3((size_t)nl * bst3, 0.0f);
+  std::vector<float> bias3((((size_t)nl * bst3 + 1023) / 1024) * 1024, 0.0f);  // whole 4 KB copy rounds
   for (int i = 0; i < H; ++i) bias3[i] = b0[i];
   for (int b = 0; b < nb; ++b)
     for (int l = 0; l < 2; ++l)

@@ -11,6 +11,7 @@
 //   1  + weight fragments from LDS
 //   2  + activation split in the vector ALU
 //   3  + the weights streamed global -> LDS by LDS-DMA (2 k-steps per ring slot, one barrier per slot)
+//   4  as 3, two output tiles at a time so that consecutive matrix instructions use different accumulators
 // Prints f32-equivalent TFLOP/s (2*rows*in*out per layer) for the whole chip.
 //   hipcc -O3 --offload-arch=gfx950 -o split_rate split_rate.hip && ./split_rate
 #include <hip/hip_runtime.h>
@@ -88,6 +89,19 @@ k(float* out, int layers, const u32x4* gsrc, unsigned gmask) {
         split8(v, b0, b1, b2);
       }
       const u32x4* wl = lds + slot * (SLOT_BYTES / 16) + (ks & 1) * (8 * 3 * 64) + lane;
+      if (V == 4) {  // two tiles at a time, consecutive matrix instructions on different accumulators
+#pragma unroll
+        for (int t = 0; t < 8; t += 2) {
+          const u32x4 c0 = wl[(t * 3 + 0) * 64], c1 = wl[(t * 3 + 1) * 64], c2 = wl[(t * 3 + 2) * 64];
+          const u32x4 d0 = wl[(t * 3 + 3) * 64], d1 = wl[(t * 3 + 4) * 64], d2 = wl[(t * 3 + 5) * 64];
+          MFMA(c0, b0, acc[t]); MFMA(d0, b0, acc[t + 1]);
+          MFMA(c0, b1, acc[t]); MFMA(d0, b1, acc[t + 1]);
+          MFMA(c1, b0, acc[t]); MFMA(d1, b0, acc[t + 1]);
+          MFMA(c0, b2, acc[t]); MFMA(d0, b2, acc[t + 1]);
+          MFMA(c1, b1, acc[t]); MFMA(d1, b1, acc[t + 1]);
+          MFMA(c2, b0, acc[t]); MFMA(d2, b0, acc[t + 1]);
+        }
+      } else {
 #pragma unroll
       for (int t = 0; t < 8; ++t) {
         if (V >= 1) { a0 = wl[(t * 3 + 0) * 64]; a1 = wl[(t * 3 + 1) * 64]; a2 = wl[(t * 3 + 2) * 64]; }
@@ -97,6 +111,7 @@ k(float* out, int layers, const u32x4* gsrc, unsigned gmask) {
         MFMA(a0, b2, acc[t]);
         MFMA(a1, b1, acc[t]);
         MFMA(a2, b0, acc[t]);
+      }
       }
     }
     // next layer: the accumulators become the activations (bias / ReLU would go here)
@@ -142,5 +157,8 @@ int main(int argc, char** argv) {
   run<3>(blocks, layers, 2 << 20);
   run<3>(blocks, layers, 4 << 20);
   run<3>(blocks, layers, 32 << 20);
+  run<4>(blocks, layers, 4 << 20);
+  run<3>(blocks, layers, 4 << 20);
+  run<4>(blocks, layers, 4 << 20);
   return 0;
 }

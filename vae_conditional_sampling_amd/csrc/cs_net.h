@@ -10,11 +10,13 @@
 struct CsLayer {
   cs_layer_desc d;
   int64_t wp_off;  // offset (floats) of the MFMA-packed weights in the device blob, -1: direct kernel
+  int64_t wp3_off; // offset (bf16 entries) of the split-bf16 packed weights in d_blob3, -1: none
 };
 
 struct CsProgram {
   std::vector<CsLayer> layers;
   float* d_blob = nullptr;   // caller's blob followed by the packed weights
+  uint16_t* d_blob3 = nullptr;  // split-bf16 packed weights of the same-size 3x3 convolutions
   int in_dim = 0, out_dim = 0;
   int64_t buf_elems[CS_NET_NBUF] = {0};  // floats per network row of every buffer
   // workspace (scratch buffers 1..4, staged input, raw output), grown on demand

@@ -28,6 +28,7 @@ struct CsConvArgs {
   const float* in;    // [n, hin, win, cin]
   const float* w;     // packed [tap][cin_p/32][cout_p][32] (mfma; _p = padded to 32, zero filled) or
                       // torch [cout][cin][k][k] (direct)
+  const uint16_t* w3; // split-bf16 packed [tap][cin/32][cout_p][term 3][32 k] (see cs_conv3x3_halo_split_kernel) or null
   const float* bias;  // [cout] or null
   const float* res;   // [n, hout, wout, cout] or null
   float* out;
@@ -305,6 +306,285 @@ __global__ void __launch_bounds__(256) cs_conv3x3_halo_kernel(const CsConvArgs a
   conv_store<CT>(a, acc, gp, blockIdx.y * (CT * 32), h);
 }
 
+// Split-bf16 variant of cs_conv3x3_halo_kernel: every f32 operand is split exactly into three bf16
+// terms and a product is accumulated in f32 from the six leading term products on
+// v_mfma_f32_32x32x16_bf16 (float32-equivalent results at 6/16 of the matrix time; the arithmetic
+// of cs_mlp_split_kernel.inc).  The weights are split on the host; the halo tile is split as it is
+// staged (once per 32-channel chunk, reused by the 9 taps).  LDS rows are [term][32 k] bf16 = 192
+// bytes; a lane's 8 consecutive k of k-step s are the 16-byte slot 2s + (lane >> 5), stored at slot
+// ^ ((row >> 2) & 3) so that 16 consecutive rows fall into 16 different bank groups.
+typedef unsigned u32x4n __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2n __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8n __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2n __attribute__((ext_vector_type(2)));
+typedef float f32x2n __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned conv_cvt_pk(float lo, float hi) {
+  return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2n){lo, hi}, bf16x2n));
+}
+template <int CT>
+__global__ void __launch_bounds__(256) cs_conv3x3_halo_split_kernel(const CsConvArgs a, int NR, int NP) {
+  constexpr int ROWB = 192, W_B = CT * 32 * ROWB;
+  constexpr int NPC = (W_B / 16 + 255) / 256;  // 16-byte pieces of a weight tile per thread
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+  unsigned char* s_w = s_raw;               // [2][CT*32][ROWB]
+  unsigned char* s_halo = s_raw + 2 * W_B;  // [NR][ROWB]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = lane >> 5, l31 = lane & 31, c4 = tid & 7;
+  const int W = a.win, H = a.hin;
+  const int ncc = a.cin >> 5;
+  const int64_t p0 = (int64_t)blockIdx.x * 128;
+  const unsigned char* wblk = (const unsigned char*)a.w3 + (int64_t)blockIdx.y * W_B;
+
+  const int64_t gp = p0 + wave * 32 + l31;
+  unsigned tapmask = 0;
+  {
+    const int hw = H * W;
+    const int64_t g = gp < a.npix ? gp : 0;
+    const int rem = (int)(g % hw);
+    const int oh = rem / W, ow = rem - oh * W;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int ih = oh + t / 3 - 1, iw = ow + t % 3 - 1;
+      if (gp < a.npix && ih >= 0 && ih < H && iw >= 0 && iw < W) tapmask |= 1u << t;
+    }
+  }
+
+  f32x16 acc[CT];
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[ct][r] = 0.0f;
+
+  constexpr int NPMAX = 8;
+  f32x4 rh[NPMAX];
+  u32x4n rw[NPC];
+  auto fetch_halo = [&](int cc) {
+#pragma unroll
+    for (int p = 0; p < NPMAX; ++p) {
+      const int row = (tid >> 3) + 32 * p;
+      const int64_t q = p0 - (W + 1) + row;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (p < NP && row < NR && q >= 0 && q < a.npix) v = *(const f32x4*)(a.in + q * a.cin + cc * 32 + c4 * 4);
+      rh[p] = v;
+    }
+  };
+  auto stash_halo = [&]() {
+#pragma unroll
+    for (int p = 0; p < NPMAX; ++p) {
+      const int row = (tid >> 3) + 32 * p;
+      if (p < NP && row < NR) {
+        // 4 consecutive k of one row -> 3 terms x 4 bf16
+        const f32x4 v = rh[p];
+        const unsigned a0 = conv_cvt_pk(v.x, v.y), b0 = conv_cvt_pk(v.z, v.w);
+        const float r0 = v.x - __uint_as_float(a0 << 16), r1 = v.y - __uint_as_float(a0 & 0xffff0000u);
+        const float r2 = v.z - __uint_as_float(b0 << 16), r3 = v.w - __uint_as_float(b0 & 0xffff0000u);
+        const unsigned a1 = conv_cvt_pk(r0, r1), b1 = conv_cvt_pk(r2, r3);
+        const unsigned a2 = conv_cvt_pk(r0 - __uint_as_float(a1 << 16), r1 - __uint_as_float(a1 & 0xffff0000u));
+        const unsigned b2 = conv_cvt_pk(r2 - __uint_as_float(b1 << 16), r3 - __uint_as_float(b1 & 0xffff0000u));
+        unsigned char* dst = s_halo + row * ROWB + (((c4 >> 1) ^ ((row >> 2) & 3)) << 4) + ((c4 & 1) << 3);
+        *(u32x2n*)(dst) = u32x2n{a0, b0};
+        *(u32x2n*)(dst + 64) = u32x2n{a1, b1};
+        *(u32x2n*)(dst + 128) = u32x2n{a2, b2};
+      }
+    }
+  };
+  auto fetch_w = [&](int t) {
+    const unsigned char* wt = wblk + (int64_t)t * a.cout_p * ROWB;
+#pragma unroll
+    for (int i = 0; i < NPC; ++i) {
+      const int idx = tid + 256 * i;
+      if (idx < W_B / 16) rw[i] = *(const u32x4n*)(wt + idx * 16);
+    }
+  };
+  auto stash_w = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < NPC; ++i) {
+      const int idx = tid + 256 * i;
+      if (idx < W_B / 16) *(u32x4n*)(s_w + buf * W_B + idx * 16) = rw[i];
+    }
+  };
+
+  fetch_halo(0);
+  fetch_w(0);
+  const int swzA = (l31 >> 2) & 3;
+  int step = 0;
+  for (int cc = 0; cc < ncc; ++cc) {
+    __syncthreads();  // every read of the previous halo tile is done
+    stash_halo();
+    for (int tap = 0; tap < 9; ++tap, ++step) {
+      const int buf = step & 1;
+      stash_w(buf);  // this stage was last read two steps ago, behind the previous step's barrier
+      __syncthreads();
+      if (tap < 8) {
+        fetch_w((tap + 1) * ncc + cc);
+      } else if (cc + 1 < ncc) {
+        fetch_w(cc + 1);
+        fetch_halo(cc + 1);
+      }
+      const int rowB = wave * 32 + l31 + (tap / 3) * W + (tap % 3);
+      const unsigned char* bp = s_halo + rowB * ROWB;
+      const int swzB = (rowB >> 2) & 3;
+      const unsigned char* ap = s_w + buf * W_B + l31 * ROWB;
+      const bool inside = (tapmask >> tap) & 1u;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const int slot = 2 * s + h;
+        u32x4n b[3];
+#pragma unroll
+        for (int tm = 0; tm < 3; ++tm) {
+          b[tm] = *(const u32x4n*)(bp + tm * 64 + ((slot ^ swzB) << 4));
+          if (!inside) b[tm] = u32x4n{0u, 0u, 0u, 0u};
+        }
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+          u32x4n w[3];
+#pragma unroll
+          for (int tm = 0; tm < 3; ++tm) w[tm] = *(const u32x4n*)(ap + ct * 32 * ROWB + tm * 64 + ((slot ^ swzA) << 4));
+#define CS_CONV_MFMA(A_, B_) \
+  acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8n, A_), __builtin_bit_cast(bf16x8n, B_), acc[ct], 0, 0, 0)
+          CS_CONV_MFMA(w[0], b[0]);
+          CS_CONV_MFMA(w[0], b[1]);
+          CS_CONV_MFMA(w[1], b[0]);
+          CS_CONV_MFMA(w[0], b[2]);
+          CS_CONV_MFMA(w[1], b[1]);
+          CS_CONV_MFMA(w[2], b[0]);
+#undef CS_CONV_MFMA
+        }
+      }
+    }
+  }
+  conv_store<CT>(a, acc, gp, blockIdx.y * (CT * 32), h);
+}
+
+// Split-bf16 variant of cs_conv_mfma_kernel (any kernel size / stride / upsampling, linear layers):
+// the activation tile of a chunk is split into its three bf16 terms as it is staged, the weight tile
+// comes pre-split (same row layout and slot swizzle as cs_conv3x3_halo_split_kernel).
+template <int CT>
+__global__ void __launch_bounds__(256) cs_conv_mfma_split_kernel(const CsConvArgs a) {
+  constexpr int ROWB = 192, W_B = CT * 32 * ROWB;
+  constexpr int NPC = (W_B / 16 + 255) / 256;
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+  unsigned char* s_pix = s_raw;             // [128][ROWB]
+  unsigned char* s_w = s_raw + 128 * ROWB;  // [CT*32][ROWB]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = lane >> 5, l31 = lane & 31;
+  const int c4 = tid & 7;
+  const int ncc = (a.cin + 31) >> 5;
+  const bool cin_vec = (a.cin & 31) == 0;
+  const int nchunks = a.ksize * a.ksize * ncc;
+  const int hup = a.hin << a.us, wup = a.win << a.us;
+
+  int ih0[4], iw0[4];
+  int64_t base[4];
+  bool pv[4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int64_t gp = (int64_t)blockIdx.x * 128 + (tid >> 3) + 32 * p;
+    pv[p] = gp < a.npix;
+    const int64_t g = pv[p] ? gp : 0;
+    const int hw = a.hout * a.wout;
+    const int64_t n = g / hw;
+    const int rem = (int)(g - n * hw);
+    const int oh = rem / a.wout, ow = rem - oh * a.wout;
+    ih0[p] = oh * a.stride - a.pad;
+    iw0[p] = ow * a.stride - a.pad;
+    base[p] = n * a.hin * a.win;
+  }
+  const unsigned char* wblk = (const unsigned char*)a.w3 + (int64_t)blockIdx.y * W_B;
+
+  f32x16 acc[CT];
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[ct][r] = 0.0f;
+  f32x4 rp[4];
+  u32x4n rw[NPC];
+  auto fetch = [&](int t) {
+    const int tap = t / ncc, cc = t - tap * ncc;
+    const int kh = tap / a.ksize, kw = tap - kh * a.ksize;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int uh = ih0[p] + kh, uw = iw0[p] + kw;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (pv[p] && uh >= 0 && uh < hup && uw >= 0 && uw < wup) {
+        const int c0 = cc * 32 + c4 * 4;
+        const float* src = a.in + ((base[p] + (int64_t)(uh >> a.us) * a.win + (uw >> a.us)) * a.cin + c0);
+        if (cin_vec) {
+          v = *(const f32x4*)src;
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (c0 + r < a.cin) v[r] = src[r];
+        }
+      }
+      rp[p] = v;
+    }
+    const unsigned char* wt = wblk + (int64_t)t * a.cout_p * ROWB;
+#pragma unroll
+    for (int i = 0; i < NPC; ++i) {
+      const int idx = tid + 256 * i;
+      if (idx < W_B / 16) rw[i] = *(const u32x4n*)(wt + idx * 16);
+    }
+  };
+  auto stash = [&]() {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int row = (tid >> 3) + 32 * p;
+      const f32x4 v = rp[p];
+      const unsigned a0 = conv_cvt_pk(v.x, v.y), b0 = conv_cvt_pk(v.z, v.w);
+      const float r0 = v.x - __uint_as_float(a0 << 16), r1 = v.y - __uint_as_float(a0 & 0xffff0000u);
+      const float r2 = v.z - __uint_as_float(b0 << 16), r3 = v.w - __uint_as_float(b0 & 0xffff0000u);
+      const unsigned a1 = conv_cvt_pk(r0, r1), b1 = conv_cvt_pk(r2, r3);
+      const unsigned a2 = conv_cvt_pk(r0 - __uint_as_float(a1 << 16), r1 - __uint_as_float(a1 & 0xffff0000u));
+      const unsigned b2 = conv_cvt_pk(r2 - __uint_as_float(b1 << 16), r3 - __uint_as_float(b1 & 0xffff0000u));
+      unsigned char* dst = s_pix + row * ROWB + (((c4 >> 1) ^ ((row >> 2) & 3)) << 4) + ((c4 & 1) << 3);
+      *(u32x2n*)(dst) = u32x2n{a0, b0};
+      *(u32x2n*)(dst + 64) = u32x2n{a1, b1};
+      *(u32x2n*)(dst + 128) = u32x2n{a2, b2};
+    }
+#pragma unroll
+    for (int i = 0; i < NPC; ++i) {
+      const int idx = tid + 256 * i;
+      if (idx < W_B / 16) *(u32x4n*)(s_w + idx * 16) = rw[i];
+    }
+  };
+
+  fetch(0);
+  const int rowB = wave * 32 + l31;
+  const unsigned char* bp = s_pix + rowB * ROWB;
+  const int swz = (l31 >> 2) & 3;  // rowB and the weight rows differ from l31 by multiples of 32
+  const unsigned char* ap = s_w + l31 * ROWB;
+  for (int t = 0; t < nchunks; ++t) {
+    __syncthreads();  // previous chunk's reads are done
+    stash();
+    __syncthreads();
+    if (t + 1 < nchunks) fetch(t + 1);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int off = ((2 * s + h) ^ swz) << 4;
+      u32x4n b[3];
+#pragma unroll
+      for (int tm = 0; tm < 3; ++tm) b[tm] = *(const u32x4n*)(bp + tm * 64 + off);
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) {
+        u32x4n w[3];
+#pragma unroll
+        for (int tm = 0; tm < 3; ++tm) w[tm] = *(const u32x4n*)(ap + ct * 32 * ROWB + tm * 64 + off);
+#define CS_CONV_MFMA(A_, B_) \
+  acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8n, A_), __builtin_bit_cast(bf16x8n, B_), acc[ct], 0, 0, 0)
+        CS_CONV_MFMA(w[0], b[0]);
+        CS_CONV_MFMA(w[0], b[1]);
+        CS_CONV_MFMA(w[1], b[0]);
+        CS_CONV_MFMA(w[0], b[2]);
+        CS_CONV_MFMA(w[1], b[1]);
+        CS_CONV_MFMA(w[2], b[0]);
+#undef CS_CONV_MFMA
+      }
+    }
+  }
+  conv_store<CT>(a, acc, (int64_t)blockIdx.x * 128 + wave * 32 + l31, blockIdx.y * (CT * 32), h);
+}
+
 // V output channels per thread (channel fastest): any channel counts, either memory order.  V = 4
 // (cout % 4 == 0, NHWC output) stores 16 bytes per thread: the layers that land here are bound by
 // their output writes.
@@ -554,6 +834,21 @@ __global__ void __launch_bounds__(64) cs_dec_finish_kernel(const CsMlpArgs a, co
 
 inline unsigned blocks_for(int64_t n) { return (unsigned)((n + 255) / 256); }
 
+// exact 3-way bf16 split of a finite float (round to nearest even at every step): v = t0 + t1 + t2
+inline void bf16_split3(float v, uint16_t t[3]) {
+  float r = v;
+  for (int i = 0; i < 3; ++i) {
+    uint32_t u;
+    std::memcpy(&u, &r, 4);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    t[i] = (uint16_t)(u >> 16);
+    const uint32_t b = (uint32_t)t[i] << 16;
+    float f;
+    std::memcpy(&f, &b, 4);
+    r -= f;
+  }
+}
+
 int launch_conv(const CsProgram& p, const CsLayer& L, const float* in, const float* res, float* out, int64_t rows,
                 hipStream_t stream) {
   const cs_layer_desc& d = L.d;
@@ -565,8 +860,51 @@ int launch_conv(const CsProgram& p, const CsLayer& L, const float* in, const flo
   a.in_nchw = d.in_nchw; a.out_nchw = d.out_nchw;
   a.npix = rows * d.hout * d.wout;
   a.cout_p = (d.cout + 31) & ~31;
+  a.w3 = nullptr;
   if (L.wp_off >= 0) {
     a.w = p.d_blob + L.wp_off;
+    if (L.wp3_off >= 0 && cs_mlp_arith() == CS_ARITH_BF16X3) {
+      // split-bf16 arithmetic: the halo kernel for same-size 3x3 convolutions, else the generic one
+      a.w3 = p.d_blob3 + L.wp3_off;
+      const bool halo3 = d.op == CS_OP_CONV && d.ksize == 3 && d.stride == 1 && d.pad == 1 && d.upsample == 1 &&
+                         d.hin == d.hout && d.win == d.wout && d.cin % 32 == 0 && d.win + 1 <= 64;
+      const int NR = 128 + 2 * (d.win + 1), NP = (NR * 8 + 255) / 256;
+      const unsigned gx = (unsigned)((a.npix + 127) / 128);
+      int dev = 0;
+      CS_HIP(hipGetDevice(&dev));
+      CS_REQUIRE(dev >= 0 && dev < 64, "device index out of range");
+#define CS_CONV3_LAUNCH(KERNEL_, LDS_, ...)                                                                             \
+  do {                                                                                                                  \
+    static bool attr_set[64] = {};                                                                                      \
+    if (!attr_set[dev]) {                                                                                               \
+      CS_HIP(hipFuncSetAttribute((const void*)KERNEL_, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));        \
+      attr_set[dev] = true;                                                                                             \
+    }                                                                                                                   \
+    hipLaunchKernelGGL(KERNEL_, dim3(gx, a.cout_p / (32 * CT_)), dim3(256), LDS_, stream, a, ##__VA_ARGS__);            \
+  } while (0)
+      if (halo3) {
+        // 64-channel blocks: two blocks fit a CU (60 KB each), measured faster than 128-channel blocks
+        if (a.cout_p % 64 == 0) {
+          constexpr int CT_ = 2;
+          CS_CONV3_LAUNCH((cs_conv3x3_halo_split_kernel<CT_>), (size_t)(2 * CT_ * 32 + NR) * 192, NR, NP);
+        } else {
+          constexpr int CT_ = 1;
+          CS_CONV3_LAUNCH((cs_conv3x3_halo_split_kernel<CT_>), (size_t)(2 * CT_ * 32 + NR) * 192, NR, NP);
+        }
+      } else if (a.cout_p % 128 == 0) {
+        constexpr int CT_ = 4;
+        CS_CONV3_LAUNCH((cs_conv_mfma_split_kernel<CT_>), (size_t)(128 + CT_ * 32) * 192);
+      } else if (a.cout_p % 64 == 0) {
+        constexpr int CT_ = 2;
+        CS_CONV3_LAUNCH((cs_conv_mfma_split_kernel<CT_>), (size_t)(128 + CT_ * 32) * 192);
+      } else {
+        constexpr int CT_ = 1;
+        CS_CONV3_LAUNCH((cs_conv_mfma_split_kernel<CT_>), (size_t)(128 + CT_ * 32) * 192);
+      }
+#undef CS_CONV3_LAUNCH
+      CS_HIP(hipGetLastError());
+      return CS_OK;
+    }
     const bool halo = d.ksize == 3 && d.stride == 1 && d.pad == 1 && d.upsample == 1 && d.hin == d.hout &&
                       d.win == d.wout && d.cin % 32 == 0 && d.win + 1 <= 64;
     const int NR = 128 + 2 * (d.win + 1), NP = (NR * 8 + 255) / 256;
@@ -627,6 +965,7 @@ extern "C" int cs_debug_set_workspace_budget(int64_t bytes) {
 void cs_prog_destroy(CsProgram* p) {
   if (!p) return;
   if (p->d_blob) (void)hipFree(p->d_blob);
+  if (p->d_blob3) (void)hipFree(p->d_blob3);
   if (p->ws) (void)hipFree(p->ws);
   delete p;
 }
@@ -644,6 +983,7 @@ extern "C" int cs_net_create(const cs_layer_desc* layers, int32_t n_layers, cons
   p->buf_elems[CS_NET_BUF_IN] = in_dim;
   p->buf_elems[CS_NET_BUF_OUT] = out_dim;
   std::vector<float> packed;
+  std::vector<uint16_t> packed3;
   auto fail = [&](const char* msg) {
     delete p;
     return cs_fail(CS_EINVAL, std::string("cs_net_create: ") + msg);
@@ -694,6 +1034,7 @@ extern "C" int cs_net_create(const cs_layer_desc* layers, int32_t n_layers, cons
     CsLayer L;
     L.d = d;
     L.wp_off = -1;
+    L.wp3_off = -1;
     if (mfma_eligible(d)) {
       // [tap][cin_p/32][cout_p][32], zero padded
       L.wp_off = blob_floats + (int64_t)packed.size();
@@ -706,6 +1047,25 @@ extern "C" int cs_net_create(const cs_layer_desc* layers, int32_t n_layers, cons
               const int ci = cc * 32 + c;
               packed.push_back(co < d.cout && ci < d.cin ? W[((int64_t)co * d.cin + ci) * kk + tap] : 0.0f);
             }
+      {
+        // split-bf16 image of the same tiles: [tap][cin_p/32][cout_p] rows of [term 3][32 k] bf16, the 16-byte
+        // slots (8 k) of a row stored at slot ^ ((cout >> 2) & 3) as the kernels read them from LDS
+        L.wp3_off = (int64_t)packed3.size();
+        for (int tap = 0; tap < kk; ++tap)
+          for (int cc = 0; cc < ncc; ++cc)
+            for (int co = 0; co < cout_p; ++co) {
+              uint16_t row[96] = {0};
+              for (int c = 0; c < 32; ++c) {
+                const int ci = cc * 32 + c;
+                const float v = co < d.cout && ci < d.cin ? W[((int64_t)co * d.cin + ci) * kk + tap] : 0.0f;
+                uint16_t t3[3];
+                bf16_split3(v, t3);
+                const int pos = (((c >> 3) ^ ((co >> 2) & 3)) << 3) + (c & 7);
+                for (int tm = 0; tm < 3; ++tm) row[tm * 32 + pos] = t3[tm];
+              }
+              packed3.insert(packed3.end(), row, row + 96);
+            }
+      }
     }
     p->layers.push_back(L);
   }
@@ -716,6 +1076,9 @@ extern "C" int cs_net_create(const cs_layer_desc* layers, int32_t n_layers, cons
   if (e == hipSuccess) e = hipMemcpy(p->d_blob, blob, blob_floats * sizeof(float), hipMemcpyHostToDevice);
   if (e == hipSuccess && !packed.empty())
     e = hipMemcpy(p->d_blob + blob_floats, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice);
+  if (e == hipSuccess && !packed3.empty()) e = hipMalloc(&p->d_blob3, packed3.size() * sizeof(uint16_t));
+  if (e == hipSuccess && !packed3.empty())
+    e = hipMemcpy(p->d_blob3, packed3.data(), packed3.size() * sizeof(uint16_t), hipMemcpyHostToDevice);
   if (e != hipSuccess) {
     cs_prog_destroy(p);
     return cs_fail(CS_EHIP, std::string("cs_net_create: ") + hipGetErrorString(e));

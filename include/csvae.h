@@ -369,7 +369,8 @@ int cs_rng_uniform64(const cs_rng* rng, uint32_t stream_id, int64_t rows, int32_
  *                    infinite or within a factor 2^-8 of FLT_MAX give NaN where float32 gives +-inf.
  *   CS_ARITH_F32     exact float32 matrix instructions (1.66x the time).
  * The setting is process-wide and applies to launches made after the call; the environment variable
- * CSVAE_MLP_ARITH (bf16x3 | f32) gives the initial value.  Layer-program networks are not affected. */
+ * CSVAE_MLP_ARITH (bf16x3 | f32) gives the initial value.  It also selects the kernels of the matrix-core
+ * convolution / linear layers of layer-program networks (cs_net_create). */
 enum { CS_ARITH_F32 = 0, CS_ARITH_BF16X3 = 1 };
 int cs_set_mlp_arith(int arith);
 int cs_get_mlp_arith(void);

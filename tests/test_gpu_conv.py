@@ -13,6 +13,9 @@ from tests.helpers import CONV_NETS, assert_close, conv_weights, load_golden, ma
 
 pytestmark = pytest.mark.gpu
 
+from tests.helpers import arith_fixture  # noqa: E402
+mlp_arith = arith_fixture()
+
 CONV_RTOL = 2e-5
 
 

@@ -63,8 +63,7 @@ def main():
     dt = time.perf_counter() - t0
     n = T - skip
     from vae_conditional_sampling_amd import _lib
-    conv = name in ("omniglot", "mnist_gmm")          # layer programs always use the exact-f32 matrix instructions
-    ARITH = "f32" if conv else _lib.get_mlp_arith()
+    ARITH = _lib.get_mlp_arith()
     PEAK = 157.3 if ARITH == "f32" else 2500.0 / 6    # algorithmic TFLOP/s: exact f32, or dense bf16 peak / 6 term products
     print(f"{name} AC-MWG: B={B} K={K} {n} iterations {dt / n * 1e3:.3f} ms/iter  {B * K * n / dt:.3e} samples/s  "
           f"{B * K * n * flops / dt / 1e12:.1f} algorithmic TFLOP/s ({B * K * n * flops / dt / 1e12 / PEAK * 100:.1f}% of the {ARITH} ceiling {PEAK:.1f})  "

@@ -12,6 +12,7 @@
 //   2  + activation split in the vector ALU
 //   3  + the weights streamed global -> LDS by LDS-DMA (2 k-steps per ring slot, one barrier per slot)
 //   4  as 3, two output tiles at a time so that consecutive matrix instructions use different accumulators
+//   5  as 3 on v_mfma_f32_16x16x32_bf16 (16 output tiles of 16 features x two 16-row halves per 32-wide k-step)
 // Prints f32-equivalent TFLOP/s (2*rows*in*out per layer) for the whole chip.
 //   hipcc -O3 --offload-arch=gfx950 -o split_rate split_rate.hip && ./split_rate
 #include <hip/hip_runtime.h>
@@ -47,6 +48,7 @@ __device__ __forceinline__ void split8(const float* v, u32x4& s0, u32x4& s1, u32
 __device__ __forceinline__ bf16x8 as_bf(u32x4 v) { return __builtin_bit_cast(bf16x8, v); }
 
 #define MFMA(a, b, c) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(a), as_bf(b), c, 0, 0, 0)
+#define MFMA16(a, b, c) c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf(a), as_bf(b), c, 0, 0, 0)
 
 constexpr int SLOT_BYTES = 2 * 8 * 3 * 1024;  // 2 k-steps x 8 tiles x 3 splits x 1 KB
 
@@ -63,7 +65,10 @@ k(float* out, int layers, const u32x4* gsrc, unsigned gmask) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) { act[t][r] = 0.001f * (lane + r + t); acc[t][r] = 0.0f; }
   u32x4 b0 = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u}, b1 = b0, b2 = b0;
-  u32x4 a0 = b0, a1 = b0, a2 = b0;
+  u32x4 a0 = b0, a1 = b0, a2 = b0, pb0 = b0, pb1 = b0, pb2 = b0;
+  f32x4 acc4[16][2];
+#pragma unroll
+  for (int t = 0; t < 16; ++t) { acc4[t][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc4[t][1] = acc4[t][0]; }
   size_t gpos = (size_t)blockIdx.x * 977;
   for (int L = 0; L < layers; ++L) {
 #pragma unroll
@@ -89,7 +94,29 @@ k(float* out, int layers, const u32x4* gsrc, unsigned gmask) {
         split8(v, b0, b1, b2);
       }
       const u32x4* wl = lds + slot * (SLOT_BYTES / 16) + (ks & 1) * (8 * 3 * 64) + lane;
-      if (V == 4) {  // two tiles at a time, consecutive matrix instructions on different accumulators
+      if (V == 5) {
+        // the same work on v_mfma_f32_16x16x32_bf16: this k-step pair = one 32-wide k-step, 16 output tiles
+        // of 16 features, two 16-row halves of the wave's 32 rows (same LDS bytes, same count x half the cycles)
+        if (ks & 1) {
+          const u32x4* wl2 = lds + slot * (SLOT_BYTES / 16) + lane;
+#pragma unroll
+          for (int t = 0; t < 16; ++t) {
+            const u32x4 c0 = wl2[(t * 3 + 0) * 64], c1 = wl2[(t * 3 + 1) * 64], c2 = wl2[(t * 3 + 2) * 64];
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+              const u32x4 e0 = hh ? b0 : pb0, e1 = hh ? b1 : pb1, e2 = hh ? b2 : pb2;
+              MFMA16(c0, e0, acc4[t][hh]);
+              MFMA16(c0, e1, acc4[t][hh]);
+              MFMA16(c1, e0, acc4[t][hh]);
+              MFMA16(c0, e2, acc4[t][hh]);
+              MFMA16(c1, e1, acc4[t][hh]);
+              MFMA16(c2, e0, acc4[t][hh]);
+            }
+          }
+        } else {
+          pb0 = b0; pb1 = b1; pb2 = b2;
+        }
+      } else if (V == 4) {  // two tiles at a time, consecutive matrix instructions on different accumulators
 #pragma unroll
         for (int t = 0; t < 8; t += 2) {
           const u32x4 c0 = wl[(t * 3 + 0) * 64], c1 = wl[(t * 3 + 1) * 64], c2 = wl[(t * 3 + 2) * 64];
@@ -118,7 +145,12 @@ k(float* out, int layers, const u32x4* gsrc, unsigned gmask) {
 #pragma unroll
     for (int t = 0; t < 8; ++t)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { act[t][r] = fmaxf(acc[t][r], 0.0f) * 1e-3f; acc[t][r] = 0.25f; }
+      for (int r = 0; r < 16; ++r) {
+        const float v = V == 5 ? acc4[2 * t + (r >> 3)][(r >> 2) & 1][r & 3] : acc[t][r];
+        act[t][r] = fmaxf(v, 0.0f) * 1e-3f;
+        acc[t][r] = 0.25f;
+        if (V == 5) acc4[2 * t + (r >> 3)][(r >> 2) & 1][r & 3] = 0.25f;
+      }
   }
   float s = 0;
 #pragma unroll
@@ -159,6 +191,8 @@ int main(int argc, char** argv) {
   run<3>(blocks, layers, 32 << 20);
   run<4>(blocks, layers, 4 << 20);
   run<3>(blocks, layers, 4 << 20);
-  run<4>(blocks, layers, 4 << 20);
+  run<5>(blocks, layers, 4 << 20);
+  run<3>(blocks, layers, 4 << 20);
+  run<5>(blocks, layers, 4 << 20);
   return 0;
 }

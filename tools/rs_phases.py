@@ -45,9 +45,10 @@ def main():
     torch.cuda.synchronize()
     E = int(sys.argv[3]) if len(sys.argv) > 3 else 64 // (K + R)   # examples per wavefront chosen by the library
     n = (B // E) * E
+    per = 3 if E >= 3 else 2          # phase durations per statistics array (see the kernel's profile block)
     ph = []
-    for i in range(7):
-        ph.append(float(ws.stats[i // 3][:n].view(-1, E)[:, i % 3].double().mean()))
+    for i in range(7 if E >= 3 else 6):
+        ph.append(float(ws.stats[i // per][:n].view(-1, E)[:, i % per].double().mean()))
     names = ["stage q/Z", "density + log_w", "ess/perplexity", "group cdf", "draws", "idx/latents out", "impute"]
     tot = sum(ph)
     for nm, v in zip(names, ph):

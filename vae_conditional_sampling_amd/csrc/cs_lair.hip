@@ -27,9 +27,10 @@ struct CsResampleArgs {
   int NS;                // output slots of the resampling = G*c (K', or glr_pad_to when padded)
   int lds_per_wave;      // floats
   int E;                 // examples per wavefront
+  int P, logP;           // lanes per example: the power of two >= S (lane = e*P + s)
   int q_stride;          // floats between the staged proposal parameters of consecutive examples
   int z_stride;          // floats between staged latents of consecutive proposals
-  CsDiv dZd, dZq, dS, dKp, dNS, dDQ, dKimp, dMC, dmixG;  // divisors of the index arithmetic (Zq = Zd/4)
+  CsDiv dZd, dZq, dS, dKp, dNS, dDQ, dKimp, dMC, dmixG, dc;  // divisors of the index arithmetic (Zq = Zd/4)
 };
 
 // Division of a small index by a launch constant: floor(t / d) = hi32(t * ceil(2^32 / d)), exact
@@ -160,10 +161,13 @@ __global__ void __launch_bounds__(64) cs_lair_resample_kernel(const CsResampleAr
   __syncthreads();
   CS_TICK();
 
-  const int e_l = cs_div(lane, a.dS);       // example slot of this lane
-  const int s = lane - e_l * S;             // proposal
-  const bool act = e_l < ne;                // (lanes >= E*S have e_l >= E >= ne)
-  const int base = act ? e_l * S : 0;       // first lane of this example
+  // An example owns P lanes, P the power of two >= S, so that the reductions over its proposals are
+  // log2(P) butterfly steps instead of S broadcasts.
+  const int P = a.P;
+  const int e_l = lane >> a.logP;           // example slot of this lane
+  const int s = lane & (P - 1);             // proposal
+  const bool act = e_l < ne && s < S;
+  const int base = e_l * P;                 // first lane of this example
   const int64_t b = b0 + e_l;
   const int i_s = cs_div(s, a.dKp), kp_s = s - i_s * Kp;
   // Resampling group of this proposal and its position inside the group.  gr / glr / lr: group
@@ -189,20 +193,32 @@ __global__ void __launch_bounds__(64) cs_lair_resample_kernel(const CsResampleAr
     return (int)__ffsll((long long)m) - 1;
   };
 
-  // reductions over the lanes of this example (optionally only its resampling group)
+  // reductions over the lanes of this example (optionally only its resampling group); the group
+  // form walks the members, the whole-example form (also a single group) is a butterfly
+  const bool one_group = G == 1 && !ir;
   auto seg_max = [&](float x, bool grouped) {
+    if (!grouped || one_group) {
+      float m = s < S ? x : -INFINITY;
+      for (int o = P >> 1; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+      return m;
+    }
     float m = -INFINITY;
     for (int jj = 0; jj < S; ++jj) {
       const float v = __shfl(x, base + jj);
-      if (!grouped || ((gmask >> jj) & 1ull)) m = fmaxf(m, v);
+      if ((gmask >> jj) & 1ull) m = fmaxf(m, v);
     }
     return m;
   };
   auto seg_sum = [&](float x, bool grouped) {
+    if (!grouped || one_group) {
+      float t = s < S ? x : 0.0f;
+      for (int o = P >> 1; o > 0; o >>= 1) t += __shfl_xor(t, o);
+      return t;
+    }
     float t = 0.0f;
     for (int jj = 0; jj < S; ++jj) {
       const float v = __shfl(x, base + jj);
-      if (!grouped || ((gmask >> jj) & 1ull)) t += v;
+      if ((gmask >> jj) & 1ull) t += v;
     }
     return t;
   };
@@ -385,29 +401,35 @@ __global__ void __launch_bounds__(64) cs_lair_resample_kernel(const CsResampleAr
       float cn = cum / run;
       if (last_in_group) cn = 1.0f;
       const double* uin = set == 0 ? a.b.u_res : a.b.u_res2;
-      // Draw dr = g*c + t of the example.  The example's S lanes fetch / generate S draws at a
-      // time (one counter-RNG block per lane instead of one per lane and draw), then the draws
-      // are broadcast one by one.
+      // Draw d = g*c + t of the example is resolved by lane d of the example (S draws at a time):
+      // the lane fetches / generates its uniform, then the members' CDF values are broadcast one
+      // by one and every lane counts those of ITS draw's group that lie below its uniform.
       const int ND = G * c;
-      int g = 0, t = 0;
       for (int d0 = 0; d0 < ND; d0 += S) {
+        const int d = d0 + s;
+        const bool has = act && d < ND;
         double u_mine = 0.0;
-        if (act && d0 + s < ND) {
-          if (uin) u_mine = uin[b * ND + d0 + s];
-          else u_mine = cs_uniform64_elem(a.rng, set == 0 ? CS_STREAM_URES : CS_STREAM_URES2, a.rng.row_offset + b,
-                                          (uint32_t)(d0 + s));
+        if (has) {
+          if (uin) u_mine = uin[b * ND + d];
+          else u_mine = cs_uniform64_elem(a.rng, set == 0 ? CS_STREAM_URES : CS_STREAM_URES2, a.rng.row_offset + b, (uint32_t)d);
         }
-        const int nd = ND - d0 < S ? ND - d0 : S;
-        for (int jj = 0; jj < nd; ++jj) {
-          const double u = __shfl(u_mine, base + jj);
-          const unsigned long long mask = __ballot(act && g_s == g && (double)cn < u);
-          int li = __popcll(mask & ex_mask);
-          // the group's first member records the draw; output slot t*G + g ('c b k d -> b (c k) d')
-          if (act && g_s == g && li_s == 0) {
-            if (li > gsize - 1) li = gsize - 1;
-            my_idx[set * NS + t * G + g] = nth_member(li);
+        const int gd = cs_div(d, a.dc), td = d - gd * c;
+        int li = 0, cnt = 0;
+        unsigned long long gm = 0;   // members of the draw's group
+        for (int jj = 0; jj < S; ++jj) {
+          const float cj = __shfl(cn, base + jj);
+          const int gj = one_group ? 0 : __shfl(g_s, base + jj);
+          if (gj == gd) {
+            gm |= 1ull << jj;
+            ++cnt;
+            li += ((double)cj < u_mine) ? 1 : 0;
           }
-          if (++t == c) { t = 0; ++g; }
+        }
+        if (has) {
+          if (li > cnt - 1) li = cnt - 1;
+          for (int q = 0; q < li; ++q) gm &= gm - 1ull;   // li-th member of the group
+          // output slot t*G + g ('c b k d -> b (c k) d')
+          my_idx[set * NS + td * G + gd] = (int)__ffsll((long long)gm) - 1;
         }
       }
     } else {
@@ -516,11 +538,14 @@ __global__ void __launch_bounds__(64) cs_lair_resample_kernel(const CsResampleAr
 #ifdef CS_RS_PROFILE
   CS_TICK();
   __syncthreads();
-  if (lane == 0 && ne >= 3)
-    for (int i = 0; i + 1 < tn; ++i) {
-      float* dst = i < 3 ? a.b.ess : (i < 6 ? a.b.tess : a.b.perplexity);
-      dst[b0 + i % 3] = (float)(T[i + 1] - T[i]);
+  // E >= 3 examples per wave: 7 phase durations, 3 per array; E == 2: the first 6, 2 per array
+  if (lane == 0 && ne >= 2 && ne == E) {
+    const int per = E >= 3 ? 3 : 2;
+    for (int i = 0; i + 1 < tn && i < 3 * per; ++i) {
+      float* dst = i < per ? a.b.ess : (i < 2 * per ? a.b.tess : a.b.perplexity);
+      dst[b0 + i % per] = (float)(T[i + 1] - T[i]);
     }
+  }
 #endif
 }
 
@@ -726,7 +751,9 @@ extern "C" int cs_lair_resample_impute(const cs_lair_cfg* c, const cs_lair_bufs*
   a.q_stride = vec ? (((qn >> 2) | 1) << 2) : (qn | 1);
   a.z_stride = vec ? c->Zd + 4 : c->Zd + 1;
   const int per_example = 3 * a.q_stride + a.S * a.z_stride + 2 * a.NS + a.S * a.mixc;  // floats of LDS
-  a.E = 64 / a.S;
+  a.P = 1; a.logP = 0;
+  while (a.P < a.S) { a.P <<= 1; ++a.logP; }
+  a.E = 64 / a.P;
   // more examples per wavefront fill more lanes, but the LDS working set limits how many
   // wavefronts are resident; ~12 KB per wavefront measured best (MiniBooNE shape)
   while (a.E > 1 && (size_t)a.E * per_example * 4 > 12 * 1024) --a.E;
@@ -737,7 +764,7 @@ extern "C" int cs_lair_resample_impute(const cs_lair_cfg* c, const cs_lair_bufs*
   CS_REQUIRE((uint64_t)64 * c->Zd * c->Zd < (1ull << 32) && (uint64_t)64 * DQ * DQ < (1ull << 32), "D or Zd too large");
   a.dZd = cs_mkdiv(c->Zd); a.dZq = cs_mkdiv(vec ? c->Zd >> 2 : 1); a.dS = cs_mkdiv(a.S); a.dKp = cs_mkdiv(a.Kp);
   a.dNS = cs_mkdiv(a.NS); a.dDQ = cs_mkdiv(DQ); a.dKimp = cs_mkdiv(a.Kimp);
-  a.dMC = cs_mkdiv(a.mixc); a.dmixG = cs_mkdiv(a.mixG);
+  a.dMC = cs_mkdiv(a.mixc); a.dmixG = cs_mkdiv(a.mixG); a.dc = cs_mkdiv(a.c);
   const unsigned grid = (unsigned)((c->B + a.E - 1) / a.E);
   if (vec)
     hipLaunchKernelGGL(cs_lair_resample_kernel<true>, dim3(grid), dim3(64), (size_t)a.lds_per_wave * 4, (hipStream_t)stream, a);

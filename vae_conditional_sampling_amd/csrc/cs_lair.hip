@@ -159,6 +159,22 @@ __global__ void __launch_bounds__(64) cs_lair_resample_kernel(const CsResampleAr
     }
   }
   __syncthreads();
+  // Normal posteriors: the terms of a component's log-density that do not depend on the proposal,
+  // L[e][j] = sum_d log(scale_jd) + Zd * log(sqrt(2 pi)), summed once per component (in order of d)
+  // instead of once per proposal; kept in the first entry of the component's log-scale row.
+  if (!beta_q) {
+    float Lj = 0.0f;
+    const bool own = lane < ne * Kp;
+    const int ce = cs_div(lane, a.dKp), cj = lane - ce * Kp;
+    float* row = l_logs + ce * QS + cj * Zd;
+    if (own) {
+      for (int d = 0; d < Zd; ++d) Lj += row[d];
+      Lj += (float)Zd * CS_LOG_SQRT_2PI;
+    }
+    __syncthreads();
+    if (own) row[0] = Lj;
+    __syncthreads();
+  }
   CS_TICK();
 
   // An example owns P lanes, P the power of two >= S, so that the reductions over its proposals are
@@ -260,18 +276,19 @@ __global__ void __launch_bounds__(64) cs_lair_resample_kernel(const CsResampleAr
             const f32x4 zz = *(const f32x4*)(z + d);
             const f32x4 lo = *(const f32x4*)(qloc + d);
             const f32x4 iv = *(const f32x4*)(q2v + d);
-            const f32x4 ls = *(const f32x4*)(qls + d);
             float df;
-            df = zz.x - lo.x; cj += -(df * df) * iv.x - ls.x - CS_LOG_SQRT_2PI;
-            df = zz.y - lo.y; cj += -(df * df) * iv.y - ls.y - CS_LOG_SQRT_2PI;
-            df = zz.z - lo.z; cj += -(df * df) * iv.z - ls.z - CS_LOG_SQRT_2PI;
-            df = zz.w - lo.w; cj += -(df * df) * iv.w - ls.w - CS_LOG_SQRT_2PI;
+            df = zz.x - lo.x; cj -= (df * df) * iv.x;
+            df = zz.y - lo.y; cj -= (df * df) * iv.y;
+            df = zz.z - lo.z; cj -= (df * df) * iv.z;
+            df = zz.w - lo.w; cj -= (df * df) * iv.w;
           }
+          cj -= qls[0];
         } else {
           for (int d = 0; d < Zd; ++d) {
             const float df = z[d] - qloc[d];
-            cj += -(df * df) * q2v[d] - qls[d] - CS_LOG_SQRT_2PI;
+            cj -= (df * df) * q2v[d];
           }
+          cj -= qls[0];
         }
       }
       l_c[t] = cj;

@@ -69,32 +69,60 @@ __global__ void __launch_bounds__(256) cs_acmwg_prepare_kernel(const CsAcmwgArgs
   a.b.use_prior[t] = up;
 }
 
-// ---- accept: one wavefront per chain ----
+// ---- accept: LP lanes per chain (LP a power of two, 64 / LP chains per wavefront) ----
+// A lane owns quads of 4 consecutive dimensions (quad l, l + LP, ... of the chain's latent / data
+// row): one counter-RNG block yields the 4 normals (or uniforms) of a quad, so no draw is computed
+// twice, and sums over a chain are log2(LP) butterfly steps.
+template <int LP>
 __global__ void __launch_bounds__(256) cs_acmwg_accept_kernel(const CsAcmwgArgs a) {
-  const int lane = threadIdx.x & 63;
-  const int64_t t = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63, l = lane & (LP - 1);
+  const int64_t t = ((int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * (64 / LP) + (lane / LP);
   const int B = a.cfg.B, K = a.cfg.K, D = a.cfg.D, Zd = a.cfg.Zd;
-  if (t >= (int64_t)B * K) return;
-  const int64_t b = t / K;
-  const int64_t grow = a.rng.row_offset * K + t;
+  const bool live = t < (int64_t)B * K;
+  const int64_t tc = live ? t : 0;  // dead lanes compute on chain 0 and store nothing
+  const int64_t b = tc / K;
+  const int64_t grow = a.rng.row_offset * K + tc;
   const double p = a.cfg.prior_mixture_probability;
   const bool bern = a.cfg.gen_dist == CS_DIST_BERN;
   const int P = bern ? D : 2 * D;
   const bool use_hist = !(a.cfg.flags & CS_MWG_PROPOSE_FROM_CURRENT);
   const bool joint_old = (a.cfg.flags & CS_MWG_JOINT_TARGET_OLD) != 0;
+  auto csum = [&](float v) {
+#pragma unroll
+    for (int o = LP >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+  };
 
   // proposal / prior log-densities of Z_new and Z_old (:1693-1715)
   float zn_q = 0.f, zo_q = 0.f, zn_p = 0.f, zo_p = 0.f;
-  const float* q = a.b.q + t * 2 * Zd;
-  for (int d = lane; d < Zd; d += 64) {
-    const float loc = q[d], sc = q[Zd + d];
-    const float zn = a.b.Z_new[t * Zd + d], zo = a.b.Z_old[t * Zd + d];
-    zn_q += cs_normal_logpdf(zn, loc, sc);
-    zo_q += cs_normal_logpdf(zo, loc, sc);
-    zn_p += cs_stdnormal_logpdf(zn);
-    zo_p += cs_stdnormal_logpdf(zo);
+  const float* q = a.b.q + tc * 2 * Zd;
+  const float* Zn = a.b.Z_new + tc * Zd;
+  float* Zo = a.b.Z_old + tc * Zd;
+  typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));  // 16-byte access at 4-byte alignment
+  for (int d0 = 4 * l; d0 < Zd; d0 += 4 * LP) {
+    f32x4 vloc = {0.f, 0.f, 0.f, 0.f}, vsc = {1.f, 1.f, 1.f, 1.f}, vzn = vloc, vzo = vloc;
+    if (d0 + 4 <= Zd) {
+      vloc = *(const f32x4_u*)(q + d0); vsc = *(const f32x4_u*)(q + Zd + d0);
+      vzn = *(const f32x4_u*)(Zn + d0); vzo = *(const f32x4_u*)(Zo + d0);
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (d0 + r < Zd) { vloc[r] = q[d0 + r]; vsc[r] = q[Zd + d0 + r]; vzn[r] = Zn[d0 + r]; vzo[r] = Zo[d0 + r]; }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int d = d0 + r;
+      if (d < Zd) {
+        const float loc = vloc[r], sc = vsc[r];
+        const float zn = vzn[r], zo = vzo[r];
+        zn_q += cs_normal_logpdf(zn, loc, sc);
+        zo_q += cs_normal_logpdf(zo, loc, sc);
+        zn_p += cs_stdnormal_logpdf(zn);
+        zo_p += cs_stdnormal_logpdf(zo);
+      }
+    }
   }
-  zn_q = wsum(zn_q); zo_q = wsum(zo_q); zn_p = wsum(zn_p); zo_p = wsum(zo_p);
+  zn_q = csum(zn_q); zo_q = csum(zo_q); zn_p = csum(zn_p); zo_p = csum(zo_p);
   const float zn_prior = zn_p;
   if (p > 0.0) {
     const float lp = logf((float)p), lq = logf((float)(1.0 - p));
@@ -111,13 +139,13 @@ __global__ void __launch_bounds__(256) cs_acmwg_accept_kernel(const CsAcmwgArgs 
       zo_q = logf(expf(x0 - m) + expf(x1 - m)) + m;
     }
   }
-  const float zold_prior = a.b.z_old_prior_lp[t];
-  const float log_accept = (a.b.ll_new[t] + zn_prior) - (a.b.x_old_lp[t] + zold_prior) + (zo_q - zn_q);
-  const float u = a.b.u_accept ? a.b.u_accept[t] : cs_uniform_elem(a.rng, CS_STREAM_UACC, grow, 0);
+  const float zold_prior = a.b.z_old_prior_lp[tc];
+  const float log_accept = (a.b.ll_new[tc] + zn_prior) - (a.b.x_old_lp[tc] + zold_prior) + (zo_q - zn_q);
+  const float u = a.b.u_accept ? a.b.u_accept[tc] : cs_uniform_elem(a.rng, CS_STREAM_UACC, grow, 0);
   const bool acc = u < expf(log_accept);
   const float fa = acc ? 1.0f : 0.0f, fn = acc ? 0.0f : 1.0f;
 
-  if (lane == 0) {
+  if (live && l == 0) {
     a.b.accepted[t] = acc;
     a.b.log_accept[t] = log_accept;
     a.b.z_old_prior_lp[t] = zold_prior * fn + zn_prior * fa;
@@ -132,44 +160,111 @@ __global__ void __launch_bounds__(256) cs_acmwg_accept_kernel(const CsAcmwgArgs 
     }
   }
   // multiply-blend of the chain state (:1739-1743)
-  for (int d = lane; d < Zd; d += 64)
-    a.b.Z_old[t * Zd + d] = a.b.Z_old[t * Zd + d] * fn + a.b.Z_new[t * Zd + d] * fa;
+  if (live) {
+    for (int d0 = 4 * l; d0 < Zd; d0 += 4 * LP) {
+      if (d0 + 4 <= Zd) {
+        const f32x4 zo = *(const f32x4_u*)(Zo + d0), zn = *(const f32x4_u*)(Zn + d0);
+        *(f32x4_u*)(Zo + d0) = zo * fn + zn * fa;
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (d0 + r < Zd) Zo[d0 + r] = Zo[d0 + r] * fn + Zn[d0 + r] * fa;
+      }
+    }
+  }
   // x_m ~ p(x_m | z), imputation, ring write, new masked log-likelihood (:1744-1755)
   float* ring_row = nullptr;
   if (use_hist) {
     const int new_tail = (a.cfg.hist_tail + 1) % a.cfg.hist_len;
-    ring_row = a.b.ring + ((int64_t)new_tail * B * K + t) * D;
+    ring_row = a.b.ring + ((int64_t)new_tail * B * K + tc) * D;
   }
+  float* go = a.b.gen_old + tc * P;
+  const float* gn = a.b.gen_new + tc * P;
+  float* Xr = a.b.X + tc * D;
+  const uint8_t* Mr = a.b.M + b * D;
   float ll = 0.f;
-  for (int d = lane; d < D; d += 64) {
-    const float m = (float)a.b.M[b * D + d];
-    const float xo = a.b.X[t * D + d];
-    float xm, lpx;
-    if (bern) {
-      const float l = a.b.gen_old[t * P + d] * fn + a.b.gen_new[t * P + d] * fa;
-      a.b.gen_old[t * P + d] = l;
-      const float ux = a.b.eps_x ? a.b.eps_x[t * D + d] : cs_uniform_elem(a.rng, CS_STREAM_X, grow, d);
-      xm = (ux < cs_sigmoid(l)) ? 1.0f : 0.0f;
-      const float xn = xo * m + xm * (1.0f - m);
-      lpx = cs_bernoulli_logpmf(xn, l);
-      a.b.X[t * D + d] = xn;
-      if (ring_row) ring_row[d] = xn;
+  for (int d0 = 4 * l; d0 < D; d0 += 4 * LP) {
+    // inputs of the quad first (X and the generator parameters are updated in place)
+    const bool full = d0 + 4 <= D;
+    f32x4 xo = {0.f, 0.f, 0.f, 0.f}, g0o = xo, g0n = xo, g1o = {1.f, 1.f, 1.f, 1.f}, g1n = g1o, dr = xo;
+    float m[4];
+    if (full) {
+      xo = *(const f32x4_u*)(Xr + d0);
+      g0o = *(const f32x4_u*)(go + d0); g0n = *(const f32x4_u*)(gn + d0);
+      if (!bern) { g1o = *(const f32x4_u*)(go + D + d0); g1n = *(const f32x4_u*)(gn + D + d0); }
+      if (a.b.eps_x) dr = *(const f32x4_u*)(a.b.eps_x + tc * D + d0);
+      uint32_t mb;
+      __builtin_memcpy(&mb, Mr + d0, 4);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) m[r] = (float)((mb >> (8 * r)) & 0xffu);
     } else {
-      const float mean = a.b.gen_old[t * P + d] * fn + a.b.gen_new[t * P + d] * fa;
-      const float sc = a.b.gen_old[t * P + D + d] * fn + a.b.gen_new[t * P + D + d] * fa;
-      a.b.gen_old[t * P + d] = mean;
-      a.b.gen_old[t * P + D + d] = sc;
-      const float e = a.b.eps_x ? a.b.eps_x[t * D + d] : cs_normal_elem(a.rng, CS_STREAM_X, grow, d);
-      xm = mean + sc * e;
-      const float xn = xo * m + xm * (1.0f - m);
-      lpx = cs_normal_logpdf(xn, mean, sc);
-      a.b.X[t * D + d] = xn;
-      if (ring_row) ring_row[d] = xn;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int d = d0 + r;
+        const bool in = d < D;
+        m[r] = in ? (float)Mr[d] : 1.0f;
+        if (in) {
+          xo[r] = Xr[d]; g0o[r] = go[d]; g0n[r] = gn[d];
+          if (!bern) { g1o[r] = go[D + d]; g1n[r] = gn[D + d]; }
+          if (a.b.eps_x) dr[r] = a.b.eps_x[tc * D + d];
+        }
+      }
     }
-    ll += joint_old ? lpx : lpx * m;
+    if (!a.b.eps_x) {
+      uint32_t x[4];
+      cs_philox_block(a.rng, CS_STREAM_X, grow, (uint32_t)(d0 >> 2), x);
+      if (bern) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dr[r] = cs_u01f(x[r]);
+      } else {
+        dr = cs_normal4(x);
+      }
+    }
+    f32x4 b0 = xo, b1 = xo, xn4 = xo;  // blended generator parameters, new imputation
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int d = d0 + r;
+      if (d < D) {
+        float xn, lpx;
+        if (bern) {
+          const float lg = g0o[r] * fn + g0n[r] * fa;
+          const float xm = (dr[r] < cs_sigmoid(lg)) ? 1.0f : 0.0f;
+          xn = xo[r] * m[r] + xm * (1.0f - m[r]);
+          lpx = cs_bernoulli_logpmf(xn, lg);
+          b0[r] = lg;
+        } else {
+          const float mean = g0o[r] * fn + g0n[r] * fa;
+          const float sc = g1o[r] * fn + g1n[r] * fa;
+          const float xm = mean + sc * dr[r];
+          xn = xo[r] * m[r] + xm * (1.0f - m[r]);
+          lpx = cs_normal_logpdf(xn, mean, sc);
+          b0[r] = mean;
+          b1[r] = sc;
+        }
+        xn4[r] = xn;
+        ll += joint_old ? lpx : lpx * m[r];
+      }
+    }
+    if (live) {
+      if (full) {
+        *(f32x4_u*)(go + d0) = b0;
+        if (!bern) *(f32x4_u*)(go + D + d0) = b1;
+        *(f32x4_u*)(Xr + d0) = xn4;
+        if (ring_row) *(f32x4_u*)(ring_row + d0) = xn4;
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (d0 + r < D) {
+            go[d0 + r] = b0[r];
+            if (!bern) go[D + d0 + r] = b1[r];
+            Xr[d0 + r] = xn4[r];
+            if (ring_row) ring_row[d0 + r] = xn4[r];
+          }
+      }
+    }
   }
-  ll = wsum(ll);
-  if (lane == 0) a.b.x_old_lp[t] = ll;
+  ll = csum(ll);
+  if (live && l == 0) a.b.x_old_lp[t] = ll;
 }
 
 // ---- small helpers ----
@@ -316,7 +411,19 @@ extern "C" int cs_acmwg_step(const cs_mlp_t* enc, const cs_mlp_t* dec, const cs_
   d.Z = b->Z_new; d.gen = b->gen_new; d.gen_ll = b->ll_new; d.X = b->X;
   d.M = (c->flags & CS_MWG_JOINT_TARGET_NEW) ? nullptr : b->M;
   if (int rc = cs_mlp_launch(d, st)) return rc;
-  hipLaunchKernelGGL(cs_acmwg_accept_kernel, dim3((unsigned)((chains + 3) / 4)), dim3(256), 0, st, a);
+  {
+    // lanes per chain: the power of two that covers the quads of the longer of a latent and a data row
+    const int nq = ((c->D > c->Zd ? c->D : c->Zd) + 3) / 4;
+#define CS_ACCEPT(LP_)                                                                                              \
+  hipLaunchKernelGGL(cs_acmwg_accept_kernel<LP_>, dim3((unsigned)((chains + 4 * (64 / LP_) - 1) / (4 * (64 / LP_)))), \
+                     dim3(256), 0, st, a)
+    if (nq <= 4) CS_ACCEPT(4);
+    else if (nq <= 8) CS_ACCEPT(8);
+    else if (nq <= 16) CS_ACCEPT(16);
+    else if (nq <= 32) CS_ACCEPT(32);
+    else CS_ACCEPT(64);
+#undef CS_ACCEPT
+  }
   CS_HIP(hipGetLastError());
   return CS_OK;
 }

@@ -512,16 +512,32 @@ __global__ void __launch_bounds__(64) cs_lair_resample_kernel(const CsResampleAr
     // place, so a load placed after a store could not be moved ahead of it, and the item would pay
     // one memory round trip per dimension
     const float* gr = a.b.gen + rho * (bern ? 1 : 2) * D;
-    float g0[4], g1[4], xo[4], mk[4], dr[4];
+    typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));  // 16-byte access at 4-byte alignment
+    const bool full = 4 * dq + 4 <= D;
+    f32x4 g0 = {0.f, 0.f, 0.f, 0.f}, g1 = g0, xo = g0, dr = g0;
+    float mk[4];
+    if (full) {
+      g0 = *(const f32x4_u*)(gr + 4 * dq);
+      if (!bern) g1 = *(const f32x4_u*)(gr + D + 4 * dq);
+      xo = *(const f32x4_u*)(xr + 4 * dq);
+      if (a.b.eps_x) dr = *(const f32x4_u*)(a.b.eps_x + (be * Kimp + n) * D + 4 * dq);
+      uint32_t mb;
+      __builtin_memcpy(&mb, mr + 4 * dq, 4);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int d = 4 * dq + r;
-      const bool in = d < D;
-      g0[r] = in ? gr[d] : 0.0f;
-      g1[r] = (in && !bern) ? gr[D + d] : 0.0f;
-      xo[r] = in ? xr[d] : 0.0f;
-      mk[r] = in ? (float)mr[d] : 1.0f;
-      dr[r] = (in && a.b.eps_x) ? a.b.eps_x[(be * Kimp + n) * D + d] : 0.0f;
+      for (int r = 0; r < 4; ++r) mk[r] = (float)((mb >> (8 * r)) & 0xffu);
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int d = 4 * dq + r;
+        const bool in = d < D;
+        mk[r] = in ? (float)mr[d] : 1.0f;
+        if (in) {
+          g0[r] = gr[d];
+          if (!bern) g1[r] = gr[D + d];
+          xo[r] = xr[d];
+          if (a.b.eps_x) dr[r] = a.b.eps_x[(be * Kimp + n) * D + d];
+        }
+      }
     }
     if (!a.b.eps_x) {
       uint32_t x[4];
@@ -530,11 +546,10 @@ __global__ void __launch_bounds__(64) cs_lair_resample_kernel(const CsResampleAr
 #pragma unroll
         for (int r = 0; r < 4; ++r) dr[r] = cs_u01f(x[r]);
       } else {
-        const f32x4 nn = cs_normal4(x);
-        dr[0] = nn.x; dr[1] = nn.y; dr[2] = nn.z; dr[3] = nn.w;
+        dr = cs_normal4(x);
       }
     }
-    float xn[4];
+    f32x4 xn;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int d = 4 * dq + r;
@@ -548,9 +563,13 @@ __global__ void __launch_bounds__(64) cs_lair_resample_kernel(const CsResampleAr
         if (clip && !(fabsf(xn[r]) < INFINITY)) xn[r] = xo[r];
       }
     }
+    if (full) {
+      *(f32x4_u*)(xw + 4 * dq) = xn;
+    } else {
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
-      if (4 * dq + r < D) xw[4 * dq + r] = xn[r];
+      for (int r = 0; r < 4; ++r)
+        if (4 * dq + r < D) xw[4 * dq + r] = xn[r];
+    }
   }
 #ifdef CS_RS_PROFILE
   CS_TICK();

@@ -740,12 +740,21 @@ __global__ void __launch_bounds__(256) cs_dec_stage_kernel(const CsMlpArgs a, in
   const int Zd = a.Zd, nq = (Zd + 3) >> 2;
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (idx >= rows * nq) return;
-  const int64_t row = row0 + idx / nq;
-  const int c0 = (int)(idx % nq) * 4;
-  const int64_t bk = row / a.Kp;
-  const int64_t kp = row - bk * a.Kp;
-  const int64_t b = bk % a.B;
-  const int64_t i = row / ((int64_t)a.Kp * a.B);
+  int64_t row, bk, kp, b, i;
+  int c0;
+  if ((row0 + rows) * nq < ((int64_t)1 << 31)) {  // 32-bit index arithmetic (64-bit divisions cost ~100 instructions each)
+    const uint32_t r32 = (uint32_t)row0 + (uint32_t)idx / (uint32_t)nq;
+    c0 = (int)((uint32_t)idx % (uint32_t)nq) * 4;
+    const uint32_t bk32 = r32 / (uint32_t)a.Kp;
+    row = r32; bk = bk32; kp = r32 - bk32 * (uint32_t)a.Kp; b = bk32 % (uint32_t)a.B; i = bk32 / (uint32_t)a.B;
+  } else {
+    row = row0 + idx / nq;
+    c0 = (int)(idx % nq) * 4;
+    bk = row / a.Kp;
+    kp = row - bk * a.Kp;
+    b = bk % a.B;
+    i = row / ((int64_t)a.Kp * a.B);
+  }
   const float* qr = a.q + (b * a.Kp + kp) * 2 * Zd;
   const bool ovr = a.z_override != nullptr && a.z_override[row] != 0;
   f32x4 e = {0.f, 0.f, 0.f, 0.f};
@@ -755,6 +764,20 @@ __global__ void __launch_bounds__(256) cs_dec_stage_kernel(const CsMlpArgs a, in
     uint32_t x[4];
     cs_philox_block(a.rng, CS_STREAM_Z, prow, (uint32_t)(c0 >> 2), x);
     e = cs_normal4(x);
+  }
+  if (!beta && c0 + 4 <= Zd) {  // whole quad inside the row: 16-byte accesses (rows start at any multiple of 4 bytes)
+    typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));
+    f32x4 z;
+    if (ovr) {
+      z = *(const f32x4_u*)(a.z_alt + row * Zd + c0);
+    } else {
+      if (a.eps_z) e = *(const f32x4_u*)(a.eps_z + row * Zd + c0);
+      const f32x4 lo = *(const f32x4_u*)(qr + c0), sc = *(const f32x4_u*)(qr + Zd + c0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) z[r] = lo[r] + sc[r] * e[r];
+    }
+    *(f32x4_u*)(a.Z + row * Zd + c0) = z;
+    return;
   }
   for (int r = 0; r < 4; ++r) {
     const int c = c0 + r;

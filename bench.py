@@ -227,6 +227,28 @@ def main():
     if exact is not None:
         out["exact_f32"] = exact
 
+    if world == 1:
+        # Accuracy of the arithmetic in force, measured here and now: the encoder network on 4096 rows of the
+        # batch against a float64 evaluation of the same weights (torch, CPU), beside the exact-f32 kernel's
+        # error on the same rows.  max |y - y64| / max |y64|.
+        def forward64(wd, x):
+            F = torch.nn.functional
+            h = F.relu(F.linear(x, wd["W0"].double(), wd["b0"].double()))
+            for W1, b1, W2, b2 in wd["blocks"]:
+                h = F.relu(h + F.linear(F.relu(F.linear(h, W1.double(), b1.double())), W2.double(), b2.double()))
+            return F.linear(h, wd["Wf"].double(), wd["bf"].double())
+
+        xs = X[:1024].reshape(-1, D).contiguous()
+        y64 = forward64(enc_w, xs.cpu().double())
+        acc = {}
+        for name in ("bf16x3", "f32"):
+            _lib.set_mlp_arith(name)
+            y = model.var_latent_network(xs).cpu().double()
+            acc[name] = float((y - y64).abs().max() / y64.abs().max())
+        _lib.set_mlp_arith(arith)
+        out["accuracy"] = {"what": "encoder outputs, 4096 rows, max |y - y_float64| / max |y_float64|",
+                           "bf16x3": acc["bf16x3"], "exact_f32": acc["f32"]}
+
     if not args.no_cpu_baseline and world == 1:
         from oracle import cs_oracle as O  # the checker, used here only as the timed CPU baseline
         # CPU baseline: the torch-CPU oracle of this repository ("port") on a bounded sample of

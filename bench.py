@@ -227,8 +227,9 @@ def main():
     if exact is not None:
         out["exact_f32"] = exact
 
-    if world == 1:
-        # Accuracy of the arithmetic in force, measured here and now: the encoder network on 4096 rows of the
+    if not args.no_cpu_baseline and world == 1:
+        # Accuracy of the arithmetic in force, measured here and now (left out, like the CPU baseline, of the
+        # profiled --no-cpu-baseline runs, whose kernel statistics then hold the timed launches only): the encoder network on 4096 rows of the
         # batch against a float64 evaluation of the same weights (torch, CPU), beside the exact-f32 kernel's
         # error on the same rows.  max |y - y64| / max |y64|.
         def forward64(wd, x):

@@ -81,3 +81,40 @@ def test_acmwg_full_size_invariants(model):
         assert 0.0 <= float(o["acceptance"]) <= 1.0
         prev = Xt.clone()
     assert t == T - 1
+
+
+@pytest.mark.parametrize("arith", ["bf16x3", "f32"])
+def test_repeated_full_size_launches_are_bit_identical(model, arith):
+    """The same encoder / decoder launches on the same inputs, over and over: any difference is a race or a
+    missed hardware hazard inside a kernel.  (Regression: the epilogue of the fused MLP kernel once read the
+    accumulators of the final matrix instruction too early, which showed as run-to-run differences in the last
+    bits of two output columns, a few launches in a hundred.)"""
+    import ctypes as C
+    from vae_conditional_sampling_amd import _lib
+    from vae_conditional_sampling_amd.sampling import engine
+    prev = _lib.set_mlp_arith(arith)
+    try:
+        X, M = inputs(3)
+        M8 = M[:, 0].to(torch.uint8).contiguous()
+        ws = engine.lair_workspace(model, B, K, R, 1, X.device)
+        cfg = engine.lair_cfg(model, ws, weighting="dmis", scheme="gr", method="multinomial", cluster_size=0, weight_alpha=None)
+        bufs = _lib.make_bufs(X=X, M=M8, q=ws.q, Z=ws.Z, gen=ws.gen, gen_ll=ws.gen_ll)
+        L, st = _lib.lib(), _lib.current_stream()
+        he, hd = model.var_latent_network.packed().handle, model.generator_network.packed().handle
+        rng = _lib.make_rng(4, 1, 0)
+
+        def launch():
+            ws.q.fill_(-7.0)
+            ws.gen.fill_(-7.0)
+            _lib.check(L.cs_lair_encode(he, C.byref(cfg), C.byref(bufs), st))
+            _lib.check(L.cs_lair_decode(hd, C.byref(cfg), C.byref(bufs), C.byref(rng), st))
+            torch.cuda.synchronize()
+            return ws.q.clone(), ws.Z.clone(), ws.gen.clone(), ws.gen_ll.clone()
+
+        ref = launch()
+        for rep in range(25):
+            out = launch()
+            for name, a, b in zip(("q", "Z", "gen", "gen_ll"), out, ref):
+                assert torch.equal(a, b), f"launch {rep}: {name} differs from the first launch in {int((a != b).sum())} entries"
+    finally:
+        _lib.set_mlp_arith(prev)

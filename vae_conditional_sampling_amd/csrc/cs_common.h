@@ -20,9 +20,17 @@ __device__ __forceinline__ void cs_dma16(const void* sbase, unsigned lane_off, u
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %0"
                :
                : "s"(sbase), "v"(lane_off), "s"(lds_base)
-               : "memory");
+               : "memory", "m0");  // M0 is written: the compiler must not keep a value of its own in it across the copy
 }
 __device__ __forceinline__ unsigned cs_scalar_u32(unsigned v) { return __builtin_amdgcn_readfirstlane(v); }
+// Wait states between the last matrix instruction of a kernel's main loop and the first vector instruction
+// that reads its accumulators.  The compiler inserts them itself in straight-line code, but not across the
+// branch that follows the loop here: the epilogue then read the last-written accumulator registers a few
+// instructions after the matrix instruction was issued and, depending on the timing, saw them without its
+// contribution (found as run-to-run differences in the last bits of two output columns).
+__device__ __forceinline__ void cs_mfma_drain() {
+  asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+}
 #endif
 
 

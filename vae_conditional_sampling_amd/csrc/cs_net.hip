@@ -193,6 +193,7 @@ __global__ void __launch_bounds__(256) cs_conv_mfma_kernel(const CsConvArgs a) {
     }
   }
 
+  cs_mfma_drain();
 #pragma unroll
   for (int pt = 0; pt < PT; ++pt)
     conv_store<CT>(a, acc[pt], (int64_t)blockIdx.x * NPIX + wave * 32 * PT + pt * 32 + l31, blockIdx.y * (CT * 32), h);
@@ -303,6 +304,7 @@ __global__ void __launch_bounds__(256) cs_conv3x3_halo_kernel(const CsConvArgs a
       }
     }
   }
+  cs_mfma_drain();
   conv_store<CT>(a, acc, gp, blockIdx.y * (CT * 32), h);
 }
 
@@ -455,6 +457,7 @@ __global__ void __launch_bounds__(64 * NW) cs_conv3x3_halo_split_kernel(const Cs
       }
     }
   }
+  cs_mfma_drain();
   conv_store<CT>(a, acc, gp, blockIdx.y * (CT * 32), h);
 }
 
@@ -584,6 +587,7 @@ __global__ void __launch_bounds__(256) cs_conv_mfma_split_kernel(const CsConvArg
       }
     }
   }
+  cs_mfma_drain();
   conv_store<CT>(a, acc, (int64_t)blockIdx.x * 128 + wave * 32 + l31, blockIdx.y * (CT * 32), h);
 }
 

@@ -186,3 +186,18 @@ def test_multi_channel_images_take_the_channel_major_path():
     x, z = torch.randn(5, 192, generator=g), torch.randn(5, 6, generator=g)
     assert_close(enc.cuda().eval()(x.cuda()), OC.resnet_encoder_forward(enc_w, x), "encoder", CONV_RTOL)
     assert_close(dec.cuda().eval()(z.cuda()), OC.resnet_decoder_forward(dec_w, z), "decoder", CONV_RTOL)
+
+
+def test_repeated_conv_forwards_are_bit_identical():
+    """Same networks, same input, launch after launch (under both arithmetics via the module fixture): a race or
+    a missed wait between the last matrix instruction of a convolution kernel and its epilogue would show here."""
+    enc_w, dec_w = conv_weights("omni_like", 31)
+    model = make_conv_model("omni_like", enc_w, dec_w, "normal", "bern")
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(1024, 784, generator=g).cuda()
+    z = torch.randn(1024, 10, generator=g).cuda()
+    ref_e, ref_d = model.var_latent_network(x).clone(), model.generator_network(z).clone()
+    for rep in range(12):
+        e, d = model.var_latent_network(x), model.generator_network(z)
+        assert torch.equal(e, ref_e), f"encoder forward {rep} differs in {int((e != ref_e).sum())} entries"
+        assert torch.equal(d, ref_d), f"decoder forward {rep} differs in {int((d != ref_d).sum())} entries"

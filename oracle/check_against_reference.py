@@ -3,6 +3,7 @@
 TEST INFRASTRUCTURE ONLY; runs in the build container only (needs /root/reference).
 
     python oracle/check_against_reference.py            # check + (re)write tests/golden/*.npz
+    python oracle/check_against_reference.py miniboone  # only the cases whose name contains "miniboone"
 
 For every case it runs the reference package (through ``oracle/ref_harness.py``) on seeded
 inputs while recording the draw tape, feeds the same draws to ``oracle/cs_oracle.py`` and
@@ -25,6 +26,19 @@ from oracle import cs_oracle as O  # noqa: E402
 from oracle.ref_harness import DrawTape, load_reference  # noqa: E402
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+ONLY = []   # command-line arguments: substrings of the case names to (re)generate; empty = all
+
+
+def selectable(fn):
+    """Skip the case when case-name filters were given on the command line and none matches."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(ns, name, **kw):
+        if ONLY and not any(o in name for o in ONLY):
+            return None
+        return fn(ns, name, **kw)
+    return wrapper
 
 
 def ref_resfc(ns, w):
@@ -92,6 +106,7 @@ def make_inputs(B, K, D, seed, miss=0.5):
 
 
 # ----------------------------------------------------------------------------------------
+@selectable
 def case_lair(ns, name, *, B, K, R, I, D, Zd, H, nb_enc, nb_dec, seed, scheme="gr",
               weighting="dmis", method="multinomial", cluster=None, resampled_latents=False,
               iters=2, temperature=None, anneal=None, latent_dist="normal_with_eps", norm=None):
@@ -162,12 +177,19 @@ BASE_KW = dict(store_last_n_iterations=-1, store_every_n_iterations=1, imputatio
                imputation_fn="vae_samples")
 
 
+def seeded_weights(prefix, in_dim, out_dim, nb, H, seed):
+    """Fixture entry naming a network by its shape and seed instead of storing its weights: the tests regenerate
+    them with O.make_resfc_weights (full-size networks would make the fixtures megabytes of random floats)."""
+    return {f"{prefix}_seeded": np.array([in_dim, out_dim, nb, H, seed], dtype=np.int64)}
+
+
+@selectable
 def case_acmwg(ns, name, *, B, K, D, Zd, H, seed, warmup, W, T, p, nkpc=None, cluster=None, R=0, plain_mwg=False,
-               ablation=False, clip=False, temperature=None, anneal=None):
+               ablation=False, clip=False, temperature=None, anneal=None, nb_enc=1, nb_dec=1, store_weights=True):
     """AC-MWG sampler class (or, with plain_mwg, TestVAEMetropolisWithinGibbs) against the oracle."""
     from oracle import cs_oracle_samplers as S
-    enc = O.make_resfc_weights(D, 2 * Zd, 1, H, seed)
-    dec = O.make_resfc_weights(Zd, 2 * D, 1, H, seed + 1)
+    enc = O.make_resfc_weights(D, 2 * Zd, nb_enc, H, seed)
+    dec = O.make_resfc_weights(Zd, 2 * D, nb_dec, H, seed + 1)
     vae = ref_vae(ns, enc, dec)
     X, M = make_inputs(B, K, D, seed + 2)
     kw = dict(num_pseudo_warmup_iterations=W, num_mwg_iterations=T,
@@ -197,7 +219,10 @@ def case_acmwg(ns, name, *, B, K, D, Zd, H, seed, warmup, W, T, p, nkpc=None, cl
     ora = list(S.acmwg_sampler(enc, dec, X.clone(), M, src, **okw))
     assert src.pos == len(entries), "oracle did not consume the whole tape"
     assert len(ora) == len(ref_out)
-    fx = dict(flat_weights("enc", enc)); fx.update(flat_weights("dec", dec))
+    if store_weights:
+        fx = dict(flat_weights("enc", enc)); fx.update(flat_weights("dec", dec))
+    else:
+        fx = dict(seeded_weights("enc", D, 2 * Zd, nb_enc, H, seed)); fx.update(seeded_weights("dec", Zd, 2 * D, nb_dec, H, seed + 1))
     fx.update(S.tape_to_npz_dict(entries))
     accs, slots = [], []
     for t, (a, r) in enumerate(zip(ora, ref_out)):
@@ -224,6 +249,7 @@ def case_acmwg(ns, name, *, B, K, D, Zd, H, seed, warmup, W, T, p, nkpc=None, cl
     print(f"[ok] {name}  (iterations {len(ref_out)}, mean acceptance {np.mean(accs):.2f})")
 
 
+@selectable
 def case_pseudo_gibbs(ns, name, *, B, K, D, Zd, H, seed, T, clip):
     """TestVAEPseudoGibbs.sampler (test_step_vae_sampling.py:1023-1042) against the oracle."""
     from oracle import cs_oracle_samplers as S
@@ -252,6 +278,7 @@ def case_pseudo_gibbs(ns, name, *, B, K, D, Zd, H, seed, T, clip):
     print(f"[ok] {name}")
 
 
+@selectable
 def case_ir_sampler(ns, name, *, B, K, I, D, Zd, H, seed, T, scheme="gr", weighting="dmis", method="multinomial",
                     cluster=None, n_final=None):
     """TestVAEImportanceResampling (sampler + the final resampling of on_test_batch_end)."""
@@ -314,6 +341,7 @@ def check_single_sample_multinomial():
     print("[ok] single-sample multinomial = argmax(p / Exp(1))")
 
 
+@selectable
 def case_lair_sampler(ns, name, *, B, K, R, D, Zd, H, seed, T, n_final=None, freq=1, final=True, scheme="gr",
                       weighting="dmis", cluster=None, pg_warmup=0, num_hist=None, no_hist_its=None, hist_len=None):
     import tempfile, types
@@ -384,6 +412,7 @@ def case_lair_sampler(ns, name, *, B, K, R, D, Zd, H, seed, T, n_final=None, fre
     print(f"[ok] {name}")
 
 
+@selectable
 def case_mlp_norm(ns, name, *, in_dim, out_dim, nb, H, rows, seed, norm):
     """ResidualFCNetwork.forward with LayerNorm / BatchNorm residual blocks (neural_nets.py:87-103), eval mode."""
     w = O.make_resfc_weights(in_dim, out_dim, nb, H, seed, norm=norm)
@@ -398,6 +427,7 @@ def case_mlp_norm(ns, name, *, in_dim, out_dim, nb, H, rows, seed, norm):
     print(f"[ok] {name}")
 
 
+@selectable
 def case_metrics(ns, name, *, B, K, D, Zd, H, seed):
     """Per-iteration diagnostics (irwg/sampling/imputation_metrics.py:85-102,133-143,200-213)."""
     import importlib
@@ -422,6 +452,7 @@ def case_metrics(ns, name, *, B, K, D, Zd, H, seed):
 
 
 def main():
+    ONLY[:] = sys.argv[1:]
     os.makedirs(GOLDEN, exist_ok=True)
     ns = load_reference()
     torch.manual_seed(0)
@@ -438,6 +469,12 @@ def main():
               iters=1)
     case_acmwg(ns, "acmwg_irwg_warmup", B=3, K=5, D=9, Zd=4, H=64, seed=707, warmup="irwg", W=2, T=12, p=0.3,
                nkpc=4, cluster=5, R=5)
+    # the MiniBooNE AC-MWG configuration (configs/uci_miniboone/sampling_u50/..k5_mwgm_usehistrestricted_005prior_
+    # with_irwg_warmup_replenish1.yaml): D=43, Zd=32, hidden 256, encoder 5 / decoder 2 blocks, K=5, p=0.05,
+    # irwg warm-up on 20 particles + 5 replenishing proposals in clusters of 5; shortened to 2 warm-up iterations
+    # (8 yields) and 14 MWG steps
+    case_acmwg(ns, "acmwg_miniboone_config", B=16, K=5, D=43, Zd=32, H=256, seed=717, warmup="irwg", W=2, T=14,
+               p=0.05, nkpc=4, cluster=5, R=5, nb_enc=5, nb_dec=2, store_weights=False)
     case_acmwg(ns, "acmwg_pg_warmup", B=4, K=3, D=7, Zd=3, H=64, seed=808, warmup="pseudo_gibbs", W=3, T=10, p=0.05)
     case_acmwg(ns, "acmwg_nowarmup_noprior", B=4, K=2, D=6, Zd=3, H=64, seed=909, warmup="none", W=0, T=8, p=0.0)
     case_mlp_norm(ns, "mlp_layernorm", in_dim=11, out_dim=10, nb=2, H=64, rows=9, seed=545, norm="layer")

@@ -40,7 +40,20 @@ NETS = {
     "omni_like": dict(enc=dict(input_shape=(1, 28, 28), layers=[1, 1, 1, 1], layer_widths=[32, 32, 64, 64], latent_dim=2 * 10),
                       dec=dict(output_shape=(1, 28, 28), layers=[1, 1, 1, 1], layer_upscale=[7, None, None, None],
                                layer_widths=[64, 32, 32, 32], downscaled_resolution=(4, 4), latent_dim=10, upscale_factor=7)),
+    # the networks of the reference's two image configurations at their real sizes
+    # (configs/mnist_gmm/vae_convresnet3.yaml, configs/omniglot28x28_bin/vae_convresnet2.yaml)
+    "gmm_full": dict(enc=dict(input_shape=(1, 14, 14), layers=[2, 2, 2, 2], layer_widths=[32, 64, 128, 256], latent_dim=2 * 25),
+                     dec=dict(output_shape=(2, 14, 14), layers=[2, 2, 2, 2], layer_upscale=[4, 7, None, None],
+                              layer_widths=[128, 64, 32, 32], downscaled_resolution=(1, 1), latent_dim=25, upscale_factor=4)),
+    "omni_full": dict(enc=dict(input_shape=(1, 28, 28), layers=[2, 2, 2, 2], layer_widths=[64, 128, 256, 512], latent_dim=2 * 50),
+                      dec=dict(output_shape=(1, 28, 28), layers=[2, 2, 2, 2], layer_upscale=[7, None, None, None],
+                               layer_widths=[256, 128, 64, 64], downscaled_resolution=(4, 4), latent_dim=50, upscale_factor=7)),
 }
+ONLY = []   # command-line arguments: substrings of the fixture names to (re)generate; empty = all
+
+
+def wanted(name):
+    return not ONLY or any(o in name for o in ONLY)
 
 
 def make_nets(name, seed):
@@ -59,6 +72,8 @@ def ref_nets(ns, name, enc_w, dec_w):
 
 def check_forwards(ns):
     for name in NETS:
+        if not wanted(f"conv_forward_{name}"):
+            continue
         enc_w, dec_w = make_nets(name, 100)
         e, d = ref_nets(ns, name, enc_w, dec_w)
         g = torch.Generator().manual_seed(5)
@@ -80,6 +95,8 @@ def ref_vae(ns, name, enc_w, dec_w, latent_dist, gen_dist):
 
 
 def case_lair_conv(ns, name, net, *, B, K, R, I, seed, iters=2):
+    if not wanted(name):
+        return
     enc_w, dec_w = make_nets(net, seed)
     vae = ref_vae(ns, net, enc_w, dec_w, "normal_with_eps", "normal_with_eps")
     D = int(np.prod(NETS[net]["enc"]["input_shape"]))
@@ -114,6 +131,8 @@ def case_lair_conv(ns, name, net, *, B, K, R, I, seed, iters=2):
 
 def case_acmwg_conv(ns, name, net, *, B, K, seed, W, T, p, nkpc, cluster, R):
     from oracle.check_against_reference import BASE_KW
+    if not wanted(name):
+        return
     enc_w, dec_w = make_nets(net, seed)
     vae = ref_vae(ns, net, enc_w, dec_w, "normal", "bern")
     D = int(np.prod(NETS[net]["enc"]["input_shape"]))
@@ -161,11 +180,14 @@ def case_acmwg_conv(ns, name, net, *, B, K, seed, W, T, p, nkpc, cluster, R):
 
 
 def main():
+    ONLY[:] = sys.argv[1:]
     ns = load_reference()
     os.makedirs(GOLDEN, exist_ok=True)
     check_forwards(ns)
     case_lair_conv(ns, "conv_lair_gmm_like", "gmm_like", B=3, K=2, R=1, I=1, seed=300)
     case_acmwg_conv(ns, "conv_acmwg_omni_like", "omni_like", B=2, K=5, seed=400, W=2, T=8, p=0.3, nkpc=4, cluster=5, R=5)
+    case_lair_conv(ns, "conv_lair_gmm_full", "gmm_full", B=3, K=4, R=1, I=1, seed=500)
+    case_acmwg_conv(ns, "conv_acmwg_omni_full", "omni_full", B=2, K=5, seed=600, W=1, T=6, p=0.2, nkpc=4, cluster=5, R=5)
 
 
 if __name__ == "__main__":

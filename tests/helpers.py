@@ -16,6 +16,10 @@ def load_golden(name):
 
 
 def weights_from_fixture(fx, prefix):
+    if f"{prefix}_seeded" in fx:   # full-size network named by (in, out, blocks, hidden, seed): regenerate it
+        from oracle import cs_oracle as O
+        in_dim, out_dim, nb, H, seed = [int(v) for v in fx[f"{prefix}_seeded"]]
+        return O.make_resfc_weights(in_dim, out_dim, nb, H, seed)
     nb = int(fx[f"{prefix}_nb"])
     t = lambda k: torch.from_numpy(fx[k])
     blocks = [(t(f"{prefix}_blk{i}_W1"), t(f"{prefix}_blk{i}_b1"), t(f"{prefix}_blk{i}_W2"), t(f"{prefix}_blk{i}_b2"))
@@ -84,6 +88,14 @@ CONV_NETS = {
     "omni_like": dict(enc=dict(input_shape=(1, 28, 28), layers=[1, 1, 1, 1], layer_widths=[32, 32, 64, 64], latent_dim=2 * 10),
                       dec=dict(output_shape=(1, 28, 28), layers=[1, 1, 1, 1], layer_upscale=[7, None, None, None],
                                layer_widths=[64, 32, 32, 32], downscaled_resolution=(4, 4), latent_dim=10, upscale_factor=7)),
+    # the reference's MNIST-GMM and Omniglot networks at their real sizes (configs/mnist_gmm/vae_convresnet3.yaml,
+    # configs/omniglot28x28_bin/vae_convresnet2.yaml of the reference)
+    "gmm_full": dict(enc=dict(input_shape=(1, 14, 14), layers=[2, 2, 2, 2], layer_widths=[32, 64, 128, 256], latent_dim=2 * 25),
+                     dec=dict(output_shape=(2, 14, 14), layers=[2, 2, 2, 2], layer_upscale=[4, 7, None, None],
+                              layer_widths=[128, 64, 32, 32], downscaled_resolution=(1, 1), latent_dim=25, upscale_factor=4)),
+    "omni_full": dict(enc=dict(input_shape=(1, 28, 28), layers=[2, 2, 2, 2], layer_widths=[64, 128, 256, 512], latent_dim=2 * 50),
+                      dec=dict(output_shape=(1, 28, 28), layers=[2, 2, 2, 2], layer_upscale=[7, None, None, None],
+                               layer_widths=[256, 128, 64, 64], downscaled_resolution=(4, 4), latent_dim=50, upscale_factor=7)),
 }
 
 

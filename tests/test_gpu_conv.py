@@ -19,11 +19,12 @@ mlp_arith = arith_fixture()
 CONV_RTOL = 2e-5
 
 
-@pytest.mark.parametrize("net", ["gmm_like", "omni_like"])
+@pytest.mark.parametrize("net", ["gmm_like", "omni_like", "gmm_full", "omni_full"])
 def test_resnet_forward_matches_reference_golden(net):
+    """*_full are the reference's MNIST-GMM / Omniglot networks at their real sizes (256 / 512 channels)."""
     fx = load_golden(f"conv_forward_{net}")
     enc_w, dec_w = conv_weights(net, int(fx["seed"]))
-    model = make_conv_model(net, enc_w, dec_w, "normal", "normal" if net == "gmm_like" else "bern")
+    model = make_conv_model(net, enc_w, dec_w, "normal", "normal" if net.startswith("gmm") else "bern")
     x, z = torch.from_numpy(fx["x"]).cuda(), torch.from_numpy(fx["z"]).cuda()
     y = model.var_latent_network(x)
     assert y.shape == fx["enc_out"].shape
@@ -57,9 +58,10 @@ def test_wide_mlp_program_matches_oracle():
         assert_close(net(x.cuda()), O.resfc_forward(w, x), "wide mlp forward")
 
 
-def test_lair_iteration_conv_matches_reference_golden():
+@pytest.mark.parametrize("name", ["conv_lair_gmm_like", "conv_lair_gmm_full"])
+def test_lair_iteration_conv_matches_reference_golden(name):
     from vae_conditional_sampling_amd.sampling.vae_imputation import importance_resampling_gibbs_iteration
-    fx = load_golden("conv_lair_gmm_like")
+    fx = load_golden(name)
     B, K, R, I, D, Zd, iters, seed = [int(v) for v in fx["cfg"]]
     net = str(fx["net"])
     enc_w, dec_w = conv_weights(net, seed)
@@ -82,14 +84,15 @@ def test_lair_iteration_conv_matches_reference_golden():
         X = torch.from_numpy(fx[f"t{t}_X_new"]).cuda()  # continue from the reference's state
 
 
-def test_acmwg_sampler_conv_bernoulli_matches_reference_golden():
-    """Omniglot-like AC-MWG (ResNet nets, Bernoulli likelihood, irwg warm-up): the recorded draw tape
+@pytest.mark.parametrize("name", ["conv_acmwg_omni_like", "conv_acmwg_omni_full"])
+def test_acmwg_sampler_conv_bernoulli_matches_reference_golden(name):
+    """Omniglot-like / full-size Omniglot AC-MWG (ResNet nets, Bernoulli likelihood, irwg warm-up): the recorded draw tape
     of the reference's sampler class is replayed into the HIP engine.  Binary imputations, accept
     decisions and history slots are compared bit for bit."""
     from tests.test_gpu_samplers import BASE_KW, tape_source
     from vae_conditional_sampling_amd.sampling.test_step_vae_sampling import \
         TestVAEAdaptiveCollapsedMetropolisWithinGibbs as Sampler
-    fx = load_golden("conv_acmwg_omni_like")
+    fx = load_golden(name)
     B, K, D, Zd, W, T, nkpc, cluster, R, seed = [int(v) for v in fx["cfg"]]
     net = str(fx["net"])
     enc_w, dec_w = conv_weights(net, seed)

@@ -46,7 +46,7 @@ def test_oracle_lair_iteration(name):
         X = o["X_new"]
 
 
-MWG_CASES = ["acmwg_tempered_annealed", "mwg_tempered_annealed", "acmwg_irwg_warmup", "acmwg_pg_warmup", "acmwg_nowarmup_noprior", "acmwg_ablation_mwg_target",
+MWG_CASES = ["acmwg_miniboone_config", "acmwg_tempered_annealed", "mwg_tempered_annealed", "acmwg_irwg_warmup", "acmwg_pg_warmup", "acmwg_nowarmup_noprior", "acmwg_ablation_mwg_target",
              "acmwg_ablation_pg_warmup", "mwg_pg_warmup_clip", "mwg_nowarmup", "mwg_irwg_warmup"]
 
 
@@ -150,3 +150,17 @@ def test_oracle_mlp_with_block_normalisation(name):
     fx = load_golden(name)
     w = weights_from_fixture(fx, "net")
     assert_close(O.resfc_forward(w, torch.from_numpy(fx["x"])), fx["y"], "forward")
+
+
+@pytest.mark.parametrize("net", ["gmm_like", "omni_like", "gmm_full", "omni_full"])
+def test_oracle_resnet_forward(net):
+    """ResNet encoder / decoder restatement against the reference's recorded outputs (*_full: the MNIST-GMM and
+    Omniglot networks at their real sizes).  torch's CPU convolution may pick another algorithm on another host,
+    hence a tolerance instead of the bitwise match of the generating run."""
+    from oracle import cs_oracle_conv as OC
+    from tests.helpers import conv_weights
+    fx = load_golden(f"conv_forward_{net}")
+    enc_w, dec_w = conv_weights(net, int(fx["seed"]))
+    with torch.no_grad():
+        assert_close(OC.resnet_encoder_forward(enc_w, torch.from_numpy(fx["x"])), fx["enc_out"], "encoder")
+        assert_close(OC.resnet_decoder_forward(dec_w, torch.from_numpy(fx["z"])), fx["dec_out"], "decoder")

@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 from tests.helpers import arith_fixture  # noqa: E402
 mlp_arith = arith_fixture()
 
-CONV_RTOL = 2e-5
+CONV_RTOL = 1e-5
 
 
 @pytest.mark.parametrize("net", ["gmm_like", "omni_like", "gmm_full", "omni_full"])

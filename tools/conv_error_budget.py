@@ -1,0 +1,68 @@
+"""Error budget of the ResNet layer programs: how far each float32 evaluation of the same network is from a
+float64 evaluation, and how far the GPU results are from the reference's recorded float32 outputs.
+
+    python tools/conv_error_budget.py            # on a GPU box; prints a table and writes JSON to stdout's last line
+
+For every network of tests/helpers.CONV_NETS and both arithmetics of the matrix kernels it reports
+max |a - b| / (|b| + 1) of
+  gpu vs f64     the GPU forward against the float64 evaluation of the oracle's functions,
+  cpu32 vs f64   torch's CPU float32 forward (what the reference computes) against the same,
+  gpu vs golden  the GPU forward against the reference's recorded outputs (tests/golden/conv_forward_*.npz).
+The tolerance of the parity tests has to cover  (gpu vs f64) + (cpu32 vs f64): two float32 evaluations of a ~20
+layer network with different summation orders are each that far from the exact result.
+"""
+import json
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from oracle import cs_oracle_conv as OC  # noqa: E402
+from tests.helpers import CONV_NETS, conv_weights, load_golden, make_conv_model, rel_err  # noqa: E402
+from vae_conditional_sampling_amd import _lib  # noqa: E402
+
+
+def to64(w):
+    return {k: (v.double() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in w.items()}
+
+
+def main():
+    rows = []
+    for net in CONV_NETS:
+        fx = load_golden(f"conv_forward_{net}")
+        enc_w, dec_w = conv_weights(net, int(fx["seed"]))
+        g = torch.Generator().manual_seed(1)
+        D = fx["x"].shape[-1]
+        x = torch.cat([torch.from_numpy(fx["x"]).reshape(-1, D), torch.randn(58, D, generator=g)])
+        Zd = fx["z"].shape[-1]
+        z = torch.cat([torch.from_numpy(fx["z"]).reshape(-1, Zd), torch.randn(58, Zd, generator=g)])
+        n_e, n_d = fx["x"].reshape(-1, D).shape[0], fx["z"].reshape(-1, Zd).shape[0]
+        with torch.no_grad():
+            e64, d64 = OC.resnet_encoder_forward(to64(enc_w), x.double()), OC.resnet_decoder_forward(to64(dec_w), z.double())
+            e32, d32 = OC.resnet_encoder_forward(enc_w, x), OC.resnet_decoder_forward(dec_w, z)
+        for arith in ("f32", "bf16x3"):
+            prev = _lib.set_mlp_arith(arith)
+            try:
+                model = make_conv_model(net, enc_w, dec_w, "normal", "normal" if net.startswith("gmm") else "bern")
+                ge, gd = model.var_latent_network(x.cuda()).cpu(), model.generator_network(z.cuda()).cpu()
+            finally:
+                _lib.set_mlp_arith(prev)
+            rows.append(dict(net=net, arith=arith,
+                             enc_gpu_vs_f64=rel_err(ge, e64), enc_cpu32_vs_f64=rel_err(e32, e64),
+                             enc_gpu_vs_golden=rel_err(ge[:n_e], fx["enc_out"].reshape(n_e, -1)),
+                             dec_gpu_vs_f64=rel_err(gd, d64), dec_cpu32_vs_f64=rel_err(d32, d64),
+                             dec_gpu_vs_golden=rel_err(gd[:n_d], fx["dec_out"].reshape(n_d, -1)),
+                             enc_out_absmax=float(e64.abs().max()), dec_out_absmax=float(d64.abs().max())))
+    hdr = ("net", "arith", "enc_gpu_vs_f64", "enc_cpu32_vs_f64", "enc_gpu_vs_golden", "dec_gpu_vs_f64", "dec_cpu32_vs_f64",
+           "dec_gpu_vs_golden", "enc_out_absmax", "dec_out_absmax")
+    print(" ".join(f"{h:>18}" for h in hdr))
+    for r in rows:
+        print(" ".join(f"{r[h]:>18}" if isinstance(r[h], str) else f"{r[h]:18.3e}" for h in hdr))
+    print(json.dumps(rows))
+
+
+if __name__ == "__main__":
+    main()

@@ -351,6 +351,18 @@ int cs_final_resample(const float* logw, const float* Zprops, int64_t TI, int64_
                       const double* u, const cs_rng* rng, int64_t n, float* cdf_ws, int64_t* idx, float* Zout,
                       void* stream);
 
+/* cs_final_resample without a workspace argument, for callers that cannot allocate device memory (code
+ * under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc).  It has no counterpart
+ * in the reference.  The CDF workspace is a fixed 32 MiB array in the library's device memory (each GPU the
+ * library runs on holds its copy until the process ends), so B * TI * K' must not exceed 8 388 608;
+ * larger problems are rejected with CS_EINVAL (use cs_final_resample).  The call allocates nothing; the
+ * first call on a device looks the array's address up (make that call outside graph capture).  All
+ * calls on one GPU share the array: calls that overlap on one GPU (different streams) race.  Same
+ * arguments and results as cs_final_resample otherwise. */
+int cs_final_resample_static(const float* logw, const float* Zprops, int64_t TI, int64_t B, int32_t Kp,
+                             int32_t Zd, const double* u, const cs_rng* rng, int64_t n, int64_t* idx, float* Zout,
+                             void* stream);
+
 /* Draws the built-in RNG would use, written out for tests: standard normals / uniforms of
  * `stream_id` (CS_STREAM_* in csrc/cs_common.h) for rows example_offset + [0,rows) and
  * elements [0,cols). */

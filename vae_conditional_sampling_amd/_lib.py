@@ -137,6 +137,7 @@ def lib():
     L.cs_history_enqueue.argtypes = [vp, vp, i32, i32, i32, vp, i64, i32, i32, vp]
     L.cs_history_set_available.argtypes = [vp, vp, i64, i64, vp]
     L.cs_final_resample.argtypes = [vp, vp, i64, i64, i32, i32, vp, C.POINTER(cs_rng), i64, vp, vp, vp, vp]
+    L.cs_final_resample_static.argtypes = [vp, vp, i64, i64, i32, i32, vp, C.POINTER(cs_rng), i64, vp, vp, vp]
     L.cs_stdnormal_logprob_rows.argtypes = [vp, i64, i32, vp, vp]
     L.cs_decode_params.argtypes = [vp, vp, i64, i32, vp, vp]
     L.cs_gen_loglik_rows.argtypes = [vp, i32, vp, vp, i64, i32, i32, vp, vp]

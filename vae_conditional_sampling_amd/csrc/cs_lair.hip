@@ -8,6 +8,7 @@
 #include "cs_mlp.h"
 
 #include <cstring>
+#include <mutex>
 
 // ----------------------------------------------------------------------------------------
 // One wavefront per example.  Lane s < S = I*K' owns proposal s = i*K' + k'.
@@ -983,6 +984,51 @@ extern "C" int cs_final_resample(const float* logw, const float* Zprops, int64_t
   if (B == 0) return CS_OK;
   CsFinalArgs a;
   a.logw = logw; a.Zp = Zprops; a.u = u; a.rng = cs_make_philox(rng); a.cdf = cdf_ws; a.idx = idx; a.Zout = Zout;
+  a.B = B; a.TI = TI; a.n = n; a.Kp = Kp; a.Zd = Zd;
+  hipLaunchKernelGGL(cs_final_resample_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);
+  CS_HIP(hipGetLastError());
+  return CS_OK;
+}
+
+// ----------------------------------------------------------------------------------------
+// cs_final_resample for callers that may not allocate (code under HIP graph capture, serving loops):
+// the CDF workspace is a fixed array in the code object's device memory instead of a caller buffer.
+// Every GPU holds its own copy of the array at its own address; the address is looked up once per
+// device (first call there) and host code only ever uses that looked-up pointer.
+// ----------------------------------------------------------------------------------------
+#define CS_FINAL_STATIC_FLOATS (8ll << 20)  // 32 MiB per GPU: B * TI * K' <= 8 388 608
+static __device__ __align__(256) float cs_final_static_cdf[CS_FINAL_STATIC_FLOATS];
+
+static std::mutex g_final_static_mutex;
+static float* g_final_static_ptr[64];  // per device ordinal; nullptr = not looked up yet
+
+extern "C" int cs_final_resample_static(const float* logw, const float* Zprops, int64_t TI, int64_t B, int32_t Kp,
+                                        int32_t Zd, const double* u, const cs_rng* rng, int64_t n, int64_t* idx,
+                                        float* Zout, void* stream) {
+  CS_REQUIRE(logw && Zprops && idx && Zout, "null argument");
+  CS_REQUIRE(TI >= 1 && B >= 0 && Kp >= 1 && Zd >= 1 && n >= 1, "bad sizes");
+  CS_REQUIRE(TI <= CS_FINAL_STATIC_FLOATS && B <= CS_FINAL_STATIC_FLOATS &&
+                 B * TI <= CS_FINAL_STATIC_FLOATS && B * TI * Kp <= CS_FINAL_STATIC_FLOATS,
+             "cs_final_resample_static: B * TI * K' exceeds the static workspace of 8 388 608 floats; use "
+             "cs_final_resample with a caller workspace");
+  if (B == 0) return CS_OK;
+  int dev = -1;
+  CS_HIP(hipGetDevice(&dev));
+  CS_REQUIRE(dev >= 0 && dev < 64, "device ordinal out of range");
+  float* cdf;
+  {
+    std::lock_guard<std::mutex> lock(g_final_static_mutex);
+    if (!g_final_static_ptr[dev]) {
+      void* p = nullptr;
+      CS_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(cs_final_static_cdf)));
+      CS_REQUIRE(p != nullptr, "hipGetSymbolAddress returned a null address");
+      g_final_static_ptr[dev] = (float*)p;
+    }
+    cdf = g_final_static_ptr[dev];
+  }
+  // every entry of an example's CDF row is written before it is read: nothing has to start at zero
+  CsFinalArgs a;
+  a.logw = logw; a.Zp = Zprops; a.u = u; a.rng = cs_make_philox(rng); a.cdf = cdf; a.idx = idx; a.Zout = Zout;
   a.B = B; a.TI = TI; a.n = n; a.Kp = Kp; a.Zd = Zd;
   hipLaunchKernelGGL(cs_final_resample_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);
   CS_HIP(hipGetLastError());

@@ -9,14 +9,21 @@ MiniBooNE configuration (D=43, Zd=32, encoder 43->256 x5 blocks ->64, decoder 32
 blocks ->86, K=4 chains, R=1 prior-replenishing proposal, I=1, dmis / gr / multinomial).
 Every rank (one process per GPU) owns its own shard of examples; there is no collective in
 the loop.  The metric is conditional samples/s = (examples x K x steps) / seconds, summed
-over ranks (weak scaling: the per-GPU batch is fixed).
+over ranks (weak scaling: the per-GPU batch is fixed).  With --gpus N and no launcher
+(WORLD_SIZE unset) the script starts its N rank processes itself.
 
 Prints ONE JSON line on rank 0 with the roofline of the dominant kernel (the fused encoder
 MLP on the matrix cores) and a CPU baseline (the torch-CPU oracle of this repository on a bounded
 sample of the same workload).  The MLP kernel's default arithmetic builds each float32 product from
 the bf16 terms of an exact 3-way split of both operands (float32-equivalent results); `--arith f32`
 selects the exact-float32 matrix instructions, and at one GPU the line also carries that
-arithmetic's throughput ("exact_f32").
+arithmetic's throughput and roofline ("exact_f32").
+
+At one GPU the line also carries `extra` legs, each timed the same way on its own resident batch
+(`--no-extras` leaves them out): LAIR at the HEPMASS and GAS shapes (K=16), LAIR MiniBooNE through
+the sampler class at the large batch and at the reference's own batch of 512 examples, AC-MWG at
+the MiniBooNE configuration (K=5) and on the Omniglot ConvResNet VAE, LAIR on the MNIST-GMM
+ConvResNet VAE.
 """
 import argparse
 import ctypes as C
@@ -41,10 +48,284 @@ BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X dense bf16 matrix peak
 # The default arithmetic of the fused MLP kernel forms every float32 product from 6 bf16 term products
 # (exact 3-way split of both operands, float32 accumulation): its ceiling in algorithmic (float32) FLOP/s
 SPLIT_PEAK_TFLOPS = BF16_MFMA_PEAK_TFLOPS / 6.0
+# algorithmic FLOPs per image of the ConvResNet encoders / decoders (2 k^2 cin cout hout wout per convolution,
+# 2 in out per linear layer)
+CONV_FLOPS = {"omniglot": (911693824, 1230915584), "mnist_gmm": (60988672, 113640448)}
+SEED = 20220118
+BASE_KW = dict(store_last_n_iterations=-1, store_every_n_iterations=1, imputation_metric_quantiles=[],
+               compute_f1_metric=False, compute_inv_f1_metric=False, compute_bin_accuracy_metric=False,
+               compute_rmse_metric=False, compute_ssim_metric=False, compute_latent_wass_metric=False,
+               imputation_fn="vae_samples")
 
 
 def resfc_flops(i, H, nb, o):
     return 2 * (i * H + 2 * nb * H * H + H * o)
+
+
+def peak_of(arith):
+    return SPLIT_PEAK_TFLOPS if arith == "bf16x3" else F32_MFMA_PEAK_TFLOPS
+
+
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start the N rank processes here, one per GPU, before this
+    process has touched a GPU (it never does), and exit with their status.  Rank 0 prints the JSON line."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()   # counts devices without initialising the GPU runtime
+    if have < n:
+        print(f"bench.py: --gpus {n} but only {have} GPU(s) are visible; not reporting a smaller run in its place",
+              file=sys.stderr)
+        return 2
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rcs = [p.wait() for p in procs]
+    if any(rcs):
+        print(f"bench.py: rank exit codes {rcs}", file=sys.stderr)
+        return 1
+    return 0
+
+
+def synthetic_batch(B, K, D, seed, dev, binary=False, quadrants=False):
+    """Standardised synthetic data with 50 % uniform missingness (UCI shapes), or Bernoulli(0.2) pixels with two
+    of the four 14x14 quadrants missing (Omniglot shape).  Returns X[B,K,D] with missing entries filled by
+    noise, and the mask M[B,D] (True = observed)."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    if binary:
+        X_true = (torch.rand(B, D, generator=g) < 0.2).float()
+    else:
+        X_true = torch.randn(B, D, generator=g)
+    if quadrants:
+        M = torch.ones(B, 28, 28, dtype=torch.bool)
+        M[:, :14, :14] = False
+        M[:, 14:, 14:] = False
+        M = M.reshape(B, D)
+    else:
+        M = torch.rand(B, D, generator=g) > 0.5
+    M[:, 0] = True
+    X = X_true.unsqueeze(1).repeat(1, K, 1)
+    fill = (torch.rand(B, K, D, generator=g) < 0.5).float() if binary else torch.randn(B, K, D, generator=g)
+    X = (X * M.unsqueeze(1) + fill * (~M.unsqueeze(1))).to(dev).contiguous()
+    return X, M
+
+
+class LairCabi:
+    """One resident LAIR batch driven through the three C-ABI stage calls (cs_lair_encode / _decode /
+    _resample_impute), HIP events between the stages."""
+
+    def __init__(self, workload, B, rank, dev):
+        from vae_conditional_sampling_amd import _lib
+        from vae_conditional_sampling_amd.models import VAE, ResidualFCNetwork
+        from vae_conditional_sampling_amd.sampling import engine
+        self._lib = _lib
+        self.w = w = WORKLOADS[workload]
+        self.workload, self.B, self.rank = workload, B, rank
+        D, Zd, H, K, R = w["D"], w["Zd"], w["H"], w["K"], w["R"]
+        torch.manual_seed(SEED)  # random-init weights of the named architecture (torch's nn.Linear default)
+        enc = ResidualFCNetwork(D, 2 * Zd, w["nbe"], H)
+        dec = ResidualFCNetwork(Zd, 2 * D, w["nbd"], H)
+
+        def cpu_copy(net):  # float32 CPU copies for the CPU baseline leg
+            d = net.weight_dict()
+            c = lambda t: t.detach().clone()
+            return {"W0": c(d["W0"]), "b0": c(d["b0"]), "blocks": [tuple(c(t) for t in b) for b in d["blocks"]],
+                    "Wf": c(d["Wf"]), "bf": c(d["bf"])}
+
+        self.enc_w, self.dec_w = cpu_copy(enc), cpu_copy(dec)
+        self.model = model = VAE(dec, "normal_with_eps", enc, "normal_with_eps").to(dev)
+        self.X, self.M = synthetic_batch(B, K, D, SEED + 17 * rank, dev)
+        self.M8 = self.M.to(torch.uint8).to(dev).contiguous()
+        self.ws = ws = engine.lair_workspace(model, B, K, R, 1, dev)
+        self.cfg = engine.lair_cfg(model, ws, weighting="dmis", scheme="gr", method="multinomial", cluster_size=0,
+                                   weight_alpha=None)
+        self.bufs = _lib.make_bufs(X=self.X, M=self.M8, q=ws.q, Z=ws.Z, gen=ws.gen, gen_ll=ws.gen_ll, log_w=ws.log_w,
+                                   norm_log_w=ws.norm_log_w, idx=ws.idx, ess=ws.stats[0], tess=ws.stats[1],
+                                   perplexity=ws.stats[2])
+        self.L = _lib.lib()
+        self.h_enc = model.var_latent_network.packed().handle
+        self.h_dec = model.generator_network.packed().handle
+        self.stream = _lib.current_stream()
+        self.f_enc = resfc_flops(D, H, w["nbe"], 2 * Zd)
+        self.f_dec = resfc_flops(Zd, H, w["nbd"], 2 * D)
+
+    def step(self, t, events=None):
+        _lib, L = self._lib, self.L
+        rng = _lib.make_rng(SEED, t, self.rank * self.B)
+        cfg, bufs = C.byref(self.cfg), C.byref(self.bufs)
+        if events is not None:
+            events[0].record()
+        _lib.check(L.cs_lair_encode(self.h_enc, cfg, bufs, self.stream))
+        if events is not None:
+            events[1].record()
+        _lib.check(L.cs_lair_decode(self.h_dec, cfg, bufs, C.byref(rng), self.stream))
+        if events is not None:
+            events[2].record()
+        _lib.check(L.cs_lair_resample_impute(cfg, bufs, C.byref(rng), self.stream))
+        if events is not None:
+            events[3].record()
+
+    def timed(self, steps, warmup, dist=None, events=True):
+        for t in range(warmup):
+            self.step(t)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        evs = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(steps)] if events else None
+        t0 = time.perf_counter()
+        for t in range(steps):
+            self.step(warmup + t, evs[t] if events else None)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0, evs
+
+    def kernel_report(self, evs, arith):
+        """Per-stage launch times (HIP events on the launch stream) and what they are as fractions of the
+        arithmetic's ceiling."""
+        w, B = self.w, self.B
+        K, R, D, Zd = w["K"], w["R"], w["D"], w["Zd"]
+        ms = lambda a, b: sum(e[a].elapsed_time(e[b]) for e in evs) / len(evs)
+        enc_ms, dec_ms, res_ms = ms(0, 1), ms(1, 2), ms(2, 3)
+        enc_flops = self.f_enc * B * K            # algorithmic FLOPs of one encoder launch
+        dec_flops = self.f_dec * B * (K + R)
+        enc_tf = enc_flops / (enc_ms * 1e-3) / 1e12
+        dec_tf = dec_flops / (dec_ms * 1e-3) / 1e12
+        peak = peak_of(arith)
+        Kp = K + R
+        res_bytes = (Kp * 2 * Zd * 4 + Kp * Zd * 4 + Kp * 4 + K * (2 * D * 4 + D * 4) + D) + (K * D * 4 + 2 * Kp * 4 + Kp * 8 + 12)
+        split = arith == "bf16x3"
+        roofline = {"bound": "mfma", "kernel": ("cs_mlp_split_kernel" if split else "cs_mlp_kernel") + " (encoder launch)",
+                    "achieved": enc_tf, "peak": peak, "unit": "TFLOP/s", "frac": enc_tf / peak,
+                    "traffic": None, "flops_per_launch": enc_flops, "avg_launch_ms": enc_ms,
+                    "note": ("algorithmic float32 FLOPs; each is executed as 6 bf16 matrix FLOPs, so peak = dense bf16 "
+                             "peak 2500 / 6 and the executed bf16 rate is 6 x achieved") if split else
+                            "algorithmic float32 FLOPs on the exact-f32 matrix instructions"}
+        kernels = {"encoder_ms": enc_ms, "decoder_ms": dec_ms, "resample_impute_ms": res_ms,
+                   # HBM-bound stage: algorithmic bytes per example (q, Z, gen_ll, the K chosen generator rows,
+                   # X and M read; X, log-weights, normalised weights, indices, statistics written)
+                   "resample_impute_GBps": B * res_bytes / (res_ms * 1e-3) / 1e9, "resample_impute_bytes_per_example": res_bytes,
+                   "encoder_frac": enc_tf / peak, "decoder_tflops": dec_tf, "decoder_frac": dec_tf / peak,
+                   "step_flops": enc_flops + dec_flops,
+                   "step_mfma_frac": (enc_flops + dec_flops) / ((enc_ms + dec_ms + res_ms) * 1e-3) / 1e12 / peak,
+                   "mlp_arith": arith}
+        return roofline, kernels
+
+
+def mlp_vae(workload, dev):
+    from vae_conditional_sampling_amd.models import VAE, ResidualFCNetwork
+    w = WORKLOADS[workload]
+    torch.manual_seed(SEED)
+    enc = ResidualFCNetwork(w["D"], 2 * w["Zd"], w["nbe"], w["H"])
+    dec = ResidualFCNetwork(w["Zd"], 2 * w["D"], w["nbd"], w["H"])
+    return VAE(dec, "normal_with_eps", enc, "normal_with_eps").to(dev)
+
+
+def conv_vae(name, dev):
+    from vae_conditional_sampling_amd.models import VAE, ResNetDecoder, ResNetEncoder
+    torch.manual_seed(SEED)
+    if name == "omniglot":
+        enc = ResNetEncoder((1, 28, 28), [2, 2, 2, 2], [64, 128, 256, 512], 100)
+        dec = ResNetDecoder((1, 28, 28), [2, 2, 2, 2], [7, None, None, None], [256, 128, 64, 64], (4, 4), 50, 7)
+        return VAE(dec, "bern", enc, "normal").to(dev)
+    enc = ResNetEncoder((1, 14, 14), [2, 2, 2, 2], [32, 64, 128, 256], 50)
+    dec = ResNetDecoder((2, 14, 14), [2, 2, 2, 2], [4, 7, None, None], [128, 64, 32, 32], (1, 1), 25, 4)
+    return VAE(dec, "normal_with_eps", enc, "normal_with_eps").to(dev)
+
+
+def time_sampler(sampler, X0, Mk, total, skip):
+    """Wall time per iteration of a sampler generator over iterations [skip, total), device work included."""
+    t0 = None
+    for t, _ in enumerate(sampler.sampler(X0, Mk)):
+        if t == skip - 1:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / (total - skip)
+
+
+def leg_lair_class(model, B, K, R, D, T, dev, flops_per_example, arith, binary=False, final=True):
+    """LAIR through TestVAELatentAdaptiveImportanceResampling.sampler (proposals kept for the final resampling
+    as in the reference's configurations), counter RNG."""
+    from vae_conditional_sampling_amd.sampling.test_step_vae_sampling import TestVAELatentAdaptiveImportanceResampling
+    s = TestVAELatentAdaptiveImportanceResampling(
+        num_iterations=T, num_imp_samples=1, weighting_scheme="dmis", resampling_scheme="gr", resampling_method="multinomial",
+        num_prior_replenish_proposals=R, resample_final_imps=final, num_copies=K, **BASE_KW)
+    s.set_model(model)
+    s.on_test_start()
+    s.rng_seed = SEED
+    s.on_test_batch_start(None, 0)
+    X, M = synthetic_batch(B, K, D, SEED + 5, dev, binary=binary)
+    Mk = M.unsqueeze(1).to(dev)
+    skip = max(2, T // 10)
+    sec = time_sampler(s, X, Mk, T, skip)
+    tf = B * flops_per_example / sec / 1e12
+    return {"ms_per_step": sec * 1e3, "value": B * K / sec, "unit": "samples/s", "examples": B, "K": K, "R": R,
+            "iterations_timed": T - skip, "roofline": {"bound": "mfma", "achieved": tf, "peak": peak_of(arith), "unit": "TFLOP/s",
+                                                       "frac": tf / peak_of(arith), "what": "whole iteration (all kernels + host)"}}
+
+
+def leg_acmwg_class(model, B, K, D, T, dev, flops_per_chain, arith, binary=False, quadrants=False):
+    """AC-MWG steps through TestVAEAdaptiveCollapsedMetropolisWithinGibbs.sampler (no warm-up, prior mixture
+    probability 0.05, restricted-availability history on the device), counter RNG."""
+    from vae_conditional_sampling_amd.sampling.test_step_vae_sampling import TestVAEAdaptiveCollapsedMetropolisWithinGibbs
+    s = TestVAEAdaptiveCollapsedMetropolisWithinGibbs(
+        num_pseudo_warmup_iterations=0, num_mwg_iterations=T, prior_mixture_probability=0.05, warmup_method="none",
+        num_copies=K, **BASE_KW)
+    s.set_model(model)
+    s.on_test_start()
+    s.rng_seed = SEED
+    X, M = synthetic_batch(B, K, D, SEED + 6, dev, binary=binary, quadrants=quadrants)
+    Mk = M.unsqueeze(1).to(dev)
+    X0 = s.basic_imputation(X, Mk)
+    skip = max(2, T // 10)
+    sec = time_sampler(s, X0, Mk, T, skip)
+    tf = B * K * flops_per_chain / sec / 1e12
+    return {"ms_per_step": sec * 1e3, "value": B * K / sec, "unit": "chain-iterations/s", "examples": B, "K": K,
+            "iterations_timed": T - skip, "roofline": {"bound": "mfma", "achieved": tf, "peak": peak_of(arith), "unit": "TFLOP/s",
+                                                       "frac": tf / peak_of(arith), "what": "whole iteration (all kernels + host)"}}
+
+
+def extra_legs(args, arith, dev):
+    legs = {}
+    steps = max(5, args.steps // 2)
+    for name in ("hepmass", "gas"):
+        if name == args.workload:
+            continue
+        b = LairCabi(name, args.batch, 0, dev)
+        el, evs = b.timed(steps, args.warmup)
+        roof, kern = b.kernel_report(evs, arith)
+        w = b.w
+        legs[f"lair_{name}"] = {"ms_per_step": el / steps * 1e3, "value": args.batch * w["K"] * steps / el, "unit": "samples/s",
+                                "examples": args.batch, "K": w["K"], "R": w["R"], "steps": steps,
+                                "roofline": {k: roof[k] for k in ("bound", "achieved", "peak", "unit", "frac", "avg_launch_ms")},
+                                "kernels": {k: kern[k] for k in ("encoder_ms", "decoder_ms", "resample_impute_ms", "decoder_frac",
+                                                                 "step_mfma_frac", "resample_impute_GBps")}}
+        del b
+        torch.cuda.empty_cache()
+    w = WORKLOADS["miniboone"]
+    f_enc, f_dec = resfc_flops(w["D"], w["H"], w["nbe"], 2 * w["Zd"]), resfc_flops(w["Zd"], w["H"], w["nbd"], 2 * w["D"])
+    model = mlp_vae("miniboone", dev)
+    # LAIR MiniBooNE through the sampler class: at the large batch, and at the reference configuration's batch
+    legs["lair_miniboone_sampler_class"] = leg_lair_class(model, args.batch, 4, 1, 43, 40, dev, 4 * f_enc + 5 * f_dec, arith)
+    legs["lair_miniboone_sampler_class_b512"] = leg_lair_class(model, 512, 4, 1, 43, 300, dev, 4 * f_enc + 5 * f_dec, arith)
+    legs["acmwg_miniboone"] = leg_acmwg_class(model, args.batch, 5, 43, 40, dev, f_enc + f_dec, arith)
+    del model
+    torch.cuda.empty_cache()
+    fe, fd = CONV_FLOPS["omniglot"]
+    legs["acmwg_omniglot_convresnet"] = leg_acmwg_class(conv_vae("omniglot", dev), 400, 5, 784, 12, dev, fe + fd, arith,
+                                                        binary=True, quadrants=True)
+    torch.cuda.empty_cache()
+    fe, fd = CONV_FLOPS["mnist_gmm"]
+    legs["lair_mnist_gmm_convresnet"] = leg_lair_class(conv_vae("mnist_gmm", dev), 2048, 4, 1, 196, 12, dev, 4 * fe + 5 * fd, arith)
+    torch.cuda.empty_cache()
+    return legs
 
 
 def main():
@@ -55,6 +336,7 @@ def main():
     ap.add_argument("--workload", default="miniboone", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=65536, help="examples per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="only the headline workload (no `extra` legs)")
     ap.add_argument("--arith", default=None, choices=["bf16x3", "f32"],
                     help="arithmetic of the fused MLP kernel (default: the library's, bf16x3 = exact 3-way bf16 split of "
                          "the float32 operands, float32 accumulation, float32-equivalent results)")
@@ -63,7 +345,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world > 1:
+    if args.gpus > 1 and world == 1:
+        raise SystemExit(launch_ranks(args.gpus))
+    if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -73,134 +357,58 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     from vae_conditional_sampling_amd import _lib
-    from vae_conditional_sampling_amd.models import VAE, ResidualFCNetwork
-    from vae_conditional_sampling_amd.sampling import engine
 
     if args.arith:
         _lib.set_mlp_arith(args.arith)
     arith = _lib.get_mlp_arith()
-    w = WORKLOADS[args.workload]
+    bench = LairCabi(args.workload, args.batch, rank, dev)
+    w, B = bench.w, args.batch
     D, Zd, H, K, R = w["D"], w["Zd"], w["H"], w["K"], w["R"]
-    B = args.batch
-    seed = 20220118
-    torch.manual_seed(seed)  # random-init weights of the named architecture (torch's nn.Linear default)
-    enc = ResidualFCNetwork(D, 2 * Zd, w["nbe"], H)
-    dec = ResidualFCNetwork(Zd, 2 * D, w["nbd"], H)
-    def cpu_copy(net):  # float32 CPU copies for the CPU baseline leg
-        d = net.weight_dict()
-        c = lambda t: t.detach().clone()
-        return {"W0": c(d["W0"]), "b0": c(d["b0"]), "blocks": [tuple(c(t) for t in b) for b in d["blocks"]],
-                "Wf": c(d["Wf"]), "bf": c(d["bf"])}
 
-    enc_w, dec_w = cpu_copy(enc), cpu_copy(dec)
-    model = VAE(dec, "normal_with_eps", enc, "normal_with_eps").to(dev)
-
-    # synthetic standardised data, 50 % uniform missingness, this rank's shard
-    g = torch.Generator(device="cpu").manual_seed(seed + 17 * rank)
-    X_true = torch.randn(B, D, generator=g)
-    M = torch.rand(B, D, generator=g) > 0.5
-    M[:, 0] = True
-    X = X_true.unsqueeze(1).repeat(1, K, 1)
-    X = (X * M.unsqueeze(1) + torch.randn(B, K, D, generator=g) * (~M.unsqueeze(1))).to(dev).contiguous()
-    M8 = M.to(torch.uint8).to(dev).contiguous()
-
-    ws = engine.lair_workspace(model, B, K, R, 1, dev)
-    cfg = engine.lair_cfg(model, ws, weighting="dmis", scheme="gr", method="multinomial", cluster_size=0,
-                          weight_alpha=None)
-    bufs = _lib.make_bufs(X=X, M=M8, q=ws.q, Z=ws.Z, gen=ws.gen, gen_ll=ws.gen_ll, log_w=ws.log_w,
-                          norm_log_w=ws.norm_log_w, idx=ws.idx, ess=ws.stats[0], tess=ws.stats[1],
-                          perplexity=ws.stats[2])
-    L = _lib.lib()
-    h_enc = model.var_latent_network.packed().handle
-    h_dec = model.generator_network.packed().handle
-    stream = _lib.current_stream()
-
-    def step(t, events=None):
-        rng = _lib.make_rng(seed, t, rank * B)
-        if events is not None:
-            events[0].record()
-        _lib.check(L.cs_lair_encode(h_enc, C.byref(cfg), C.byref(bufs), stream))
-        if events is not None:
-            events[1].record()
-        _lib.check(L.cs_lair_decode(h_dec, C.byref(cfg), C.byref(bufs), C.byref(rng), stream))
-        if events is not None:
-            events[2].record()
-        _lib.check(L.cs_lair_resample_impute(C.byref(cfg), C.byref(bufs), C.byref(rng), stream))
-        if events is not None:
-            events[3].record()
-
-    for t in range(args.warmup):
-        step(t)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
-    t0 = time.perf_counter()
-    for t in range(args.steps):
-        step(args.warmup + t, evs[t])
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    elapsed, evs = bench.timed(args.steps, args.warmup, dist)
     if dist is not None:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
         # the only collective of the path: final imputations and log-weights are gathered once
-        gathered = torch.empty(world, *X.shape, device=dev)
-        dist.all_gather_into_tensor(gathered, X)
-        glw = torch.empty(world, *ws.log_w.shape, device=dev)
-        dist.all_gather_into_tensor(glw, ws.log_w)
+        gathered = torch.empty(world, *bench.X.shape, device=dev)
+        dist.all_gather_into_tensor(gathered, bench.X)
+        glw = torch.empty(world, *bench.ws.log_w.shape, device=dev)
+        dist.all_gather_into_tensor(glw, bench.ws.log_w)
         torch.cuda.synchronize()
-    assert torch.isfinite(X).all(), "non-finite imputations"
+    assert torch.isfinite(bench.X).all(), "non-finite imputations"
 
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
         return
 
+    roofline, kernels = bench.kernel_report(evs, arith)
+    # HBM bytes per encoder launch from the PMC counters of a profiled run of this command
+    # (tools/pmc_summary.py writes the file; null when it has not been collected for this workload and batch)
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_summary.json")) as f:
+            pmc = json.load(f)
+        if pmc.get("workload") == args.workload and pmc.get("examples_per_gpu") == B and pmc.get("mlp_arith", arith) == arith:
+            roofline["traffic"] = pmc["encoder_launch"]["hbm_bytes"]
+            roofline["traffic_source"] = ("profiles/pmc_summary.json: rocprofv3 --pmc passes of this command "
+                                          "(FETCH_SIZE / WRITE_SIZE), not collected in this run")
+    except (OSError, KeyError, ValueError):
+        pass
+
     # the same K steps on the exact-float32 matrix instructions, for comparison (outside the timed region)
     exact = None
     if arith != "f32" and world == 1:
         _lib.set_mlp_arith("f32")
-        for t in range(args.warmup):
-            step(t)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for t in range(args.steps):
-            step(args.warmup + t)
-        torch.cuda.synchronize()
-        el = time.perf_counter() - t1
+        el, evs32 = bench.timed(args.steps, args.warmup)
+        r32, k32 = bench.kernel_report(evs32, "f32")
         _lib.set_mlp_arith(arith)
-        exact = {"value": B * K * args.steps / el, "ms_per_step": el / args.steps * 1e3, "unit": "samples/s"}
+        exact = {"value": B * K * args.steps / el, "ms_per_step": el / args.steps * 1e3, "unit": "samples/s",
+                 "roofline": {k: r32[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "flops_per_launch", "avg_launch_ms")},
+                 "kernels": {k: k32[k] for k in ("encoder_ms", "decoder_ms", "resample_impute_ms", "decoder_frac", "step_mfma_frac")}}
 
-    ms = lambda a, b: sum(e[a].elapsed_time(e[b]) for e in evs) / len(evs)
-    enc_ms, dec_ms, res_ms = ms(0, 1), ms(1, 2), ms(2, 3)
-    f_enc = resfc_flops(D, H, w["nbe"], 2 * Zd)
-    f_dec = resfc_flops(Zd, H, w["nbd"], 2 * D)
-    enc_flops = f_enc * B * K            # algorithmic FLOPs of one encoder launch
-    dec_flops = f_dec * B * (K + R)
-    enc_tf = enc_flops / (enc_ms * 1e-3) / 1e12
-    dec_tf = dec_flops / (dec_ms * 1e-3) / 1e12
     value = world * B * K * args.steps / elapsed
     split = arith == "bf16x3"
-    peak = SPLIT_PEAK_TFLOPS if split else F32_MFMA_PEAK_TFLOPS
-    Kp = K + R
-    res_bytes = (Kp * 2 * Zd * 4 + Kp * Zd * 4 + Kp * 4 + K * (2 * D * 4 + D * 4) + D) + (K * D * 4 + 2 * Kp * 4 + Kp * 8 + 12)
-
-    # HBM bytes per encoder launch from the PMC counters of a profiled run of this command
-    # (tools/pmc_summary.py writes the file; null when it has not been collected)
-    traffic = None
-    try:
-        with open(os.path.join(ROOT, "profiles", "pmc_summary.json")) as f:
-            pmc = json.load(f)
-        if pmc.get("workload") == args.workload and pmc.get("examples_per_gpu") == B:
-            traffic = pmc["encoder_launch"]["hbm_bytes"]
-    except (OSError, KeyError, ValueError):
-        pass
-
     out = {
         "metric": "conditional samples/sec (N x K chains) for LAIR",
         "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -209,23 +417,16 @@ def main():
         "config": {"workload": f"uci_{args.workload} MLP-VAE LAIR (dmis/gr/multinomial), D={D} Zd={Zd} H={H} "
                                f"enc_blocks={w['nbe']} dec_blocks={w['nbd']} K={K} R={R} I=1",
                    "examples_per_gpu": B, "chains_per_gpu": B * K, "sharding": f"examples x{world}, no collective in loop"},
-        "roofline": {"bound": "mfma", "kernel": ("cs_mlp_split_kernel" if split else "cs_mlp_kernel") + " (encoder launch)",
-                     "achieved": enc_tf, "peak": peak, "unit": "TFLOP/s", "frac": enc_tf / peak,
-                     "traffic": traffic, "flops_per_launch": enc_flops, "avg_launch_ms": enc_ms,
-                     "note": ("algorithmic float32 FLOPs; each is executed as 6 bf16 matrix FLOPs, so peak = dense bf16 "
-                              "peak 2500 / 6 and the executed bf16 rate is 6 x achieved") if split else
-                             "algorithmic float32 FLOPs on the exact-f32 matrix instructions"},
-        "kernels": {"encoder_ms": enc_ms, "decoder_ms": dec_ms, "resample_impute_ms": res_ms,
-                    # HBM-bound stage: algorithmic bytes per example (q, Z, gen_ll, the K chosen generator rows,
-                    # X and M read; X, log-weights, normalised weights, indices, statistics written)
-                    "resample_impute_GBps": B * res_bytes / (res_ms * 1e-3) / 1e9, "resample_impute_bytes_per_example": res_bytes,
-                    "decoder_tflops": dec_tf, "decoder_frac": dec_tf / peak,
-                    "step_flops": enc_flops + dec_flops,
-                    "step_mfma_frac": (enc_flops + dec_flops) / ((enc_ms + dec_ms + res_ms) * 1e-3) / 1e12 / peak,
-                    "mlp_arith": arith},
+        "roofline": roofline,
+        "kernels": kernels,
     }
     if exact is not None:
         out["exact_f32"] = exact
+    try:
+        with open(os.path.join(ROOT, "roofline.json")) as f:
+            out["measured_peaks"] = json.load(f)   # what a box of this kind sustains (tools/micro/peaks.hip), for context
+    except (OSError, ValueError):
+        pass
 
     if not args.no_cpu_baseline and world == 1:
         # Accuracy of the arithmetic in force, measured here and now (left out, like the CPU baseline, of the
@@ -239,16 +440,22 @@ def main():
                 h = F.relu(h + F.linear(F.relu(F.linear(h, W1.double(), b1.double())), W2.double(), b2.double()))
             return F.linear(h, wd["Wf"].double(), wd["bf"].double())
 
-        xs = X[:1024].reshape(-1, D).contiguous()
-        y64 = forward64(enc_w, xs.cpu().double())
+        xs = bench.X[:1024].reshape(-1, D).contiguous()
+        y64 = forward64(bench.enc_w, xs.cpu().double())
         acc = {}
         for name in ("bf16x3", "f32"):
             _lib.set_mlp_arith(name)
-            y = model.var_latent_network(xs).cpu().double()
+            y = bench.model.var_latent_network(xs).cpu().double()
             acc[name] = float((y - y64).abs().max() / y64.abs().max())
         _lib.set_mlp_arith(arith)
         out["accuracy"] = {"what": "encoder outputs, 4096 rows, max |y - y_float64| / max |y_float64|",
                            "bf16x3": acc["bf16x3"], "exact_f32": acc["f32"]}
+
+    enc_w, dec_w, Xs, Ms = bench.enc_w, bench.dec_w, bench.X[:512].cpu(), bench.M[:512]
+    if not args.no_extras and world == 1:
+        del bench
+        torch.cuda.empty_cache()
+        out["extra"] = extra_legs(args, arith, dev)
 
     if not args.no_cpu_baseline and world == 1:
         from oracle import cs_oracle as O  # the checker, used here only as the timed CPU baseline
@@ -257,7 +464,7 @@ def main():
         nthreads = min(torch.get_num_threads(), 16)
         torch.set_num_threads(nthreads)
         Bc = 512
-        Xc, Mc = X[:Bc].cpu(), M[:Bc].unsqueeze(1)
+        Xc, Mc = Xs, Ms.unsqueeze(1)
         gc = torch.Generator().manual_seed(1)
         draws = {"eps_z": torch.randn(1, Bc, K + R, Zd, generator=gc),
                  "u_res": torch.rand(Bc, K + R, generator=gc, dtype=torch.float64),

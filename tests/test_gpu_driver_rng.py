@@ -110,3 +110,33 @@ def test_yaml_driver_end_to_end_lair_and_acmwg(tmp_path):
     assert not tester.history.full and tester.history.tail_idx == 4 + 9 - 1
     av = tester.history.available_timesteps.cpu()
     assert int(av.min()) >= 4 and int(av.max()) <= 4 + 9 - 1
+
+
+@pytest.mark.parametrize("config,extra", [
+    ("configs/uci_miniboone/sampling_u50/lair_k4_dmis_gr_mult_1replenish.yaml",
+     ["test_class.init_args.num_iterations=5", "test_class.init_args.store_latents=True"]),
+    ("configs/uci_miniboone/sampling_u50/acmwg_k5_005prior_irwg_warmup.yaml",
+     ["test_class.init_args.num_pseudo_warmup_iterations=2", "test_class.init_args.num_mwg_iterations=7"])])
+def test_sharded_driver_runs_reassemble_the_one_process_artifacts(tmp_path, config, extra):
+    """driver.run as rank 0 of 2 and rank 1 of 2 (one after the other in this process, no process group: the
+    gather is distributed.merge_shards) writes, once merged and cut into the one-process batches, exactly the
+    files of the unsharded run: the counter RNG is keyed by the global example index, shard boundaries need
+    not fall on batch boundaries (101 examples, batches of 32: shards of 51 and 50)."""
+    from vae_conditional_sampling_amd import distributed, driver
+    common = ["data.synthetic_num_test=150", "data.num_first_datapoints_test=101", "data.batch_size=32"] + extra
+    cfg = lambda root: driver.load_config(os.path.join(ROOT, config), common + [f"trainer.default_root_dir={root}"])
+    whole, _ = driver.run(cfg(tmp_path / "one"))
+    shards = []
+    for rank in range(2):
+        t, _ = driver.run(cfg(tmp_path / "two"), rank=rank, world_size=2)
+        assert (t.out_dir is None) == (rank == 1)
+        shards.append(t.collector.shard_arrays())
+    out2 = str(tmp_path / "two" / "merged")
+    distributed.write_batches(distributed.merge_shards(shards), 32, out2)
+    names = sorted(n for n in os.listdir(whole.out_dir) if n.startswith(("imputations_", "irwg_")))
+    assert names == sorted(os.listdir(out2)) and len(names) >= 4
+    for name in names:
+        a, b = np.load(os.path.join(whole.out_dir, name)), np.load(os.path.join(out2, name))
+        assert sorted(a.files) == sorted(b.files)
+        for k in a.files:
+            assert a[k].dtype == b[k].dtype and np.array_equal(a[k], b[k]), f"{name}[{k}] differs between the runs"

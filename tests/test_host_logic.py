@@ -239,3 +239,21 @@ def test_async_npz_writer(tmp_path):
     with pytest.raises(OSError):
         w.wait()
     w.close()
+
+
+def test_data_index_counts_positions_among_the_kept_rows(tmp_path):
+    """The reference wraps DatasetWithIndices around FullyMissingDataFilter (missing_data_module.py:436-440):
+    the index of an example is its position after fully-missing rows were dropped, 0..n_kept-1."""
+    import numpy as np
+    import torch
+    from vae_conditional_sampling_amd.data import MissingDataModule
+    os.makedirs(tmp_path / "d2", exist_ok=True)
+    np.save(tmp_path / "d2" / "test.npy", np.arange(400, dtype=np.float32).reshape(200, 2))
+    dm = MissingDataModule("d2", 16, missingness="uniform", total_miss_test=0.5, setup_seed=3, data_root=str(tmp_path),
+                           filter_fully_missing_test=True, num_first_datapoints_test=50)
+    dm.setup("test")
+    X, M, I = dm.test_data
+    assert M.any(dim=1).all() and X.shape[0] == 50
+    assert torch.equal(I, torch.arange(50))
+    # rows were really dropped: the 50 kept rows are not the first 50 rows of the file
+    assert not torch.equal(X[:, 0], torch.arange(0, 100, 2, dtype=torch.float32))

@@ -125,10 +125,12 @@ class MissingDataModule:
             M = quadrant_missingness_mask(X.shape[0], hp.img_dims, hp.total_miss_test, rng)
         else:
             raise NotImplementedError(f"missingness {hp.missingness!r} (only 'uniform', 'quadrants' and 'nan_miss')")
-        I = torch.arange(X.shape[0], dtype=torch.int64)
         if hp.filter_fully_missing_test:
             keep = M.any(dim=1)
-            X, M, I = X[keep], M[keep], I[keep]
+            X, M = X[keep], M[keep]
+        # DatasetWithIndices wraps the filtered dataset (missing_data_module.py:436-440 of the reference):
+        # the data index is the position among the kept rows
+        I = torch.arange(X.shape[0], dtype=torch.int64)
         if hp.num_first_datapoints_test is not None:
             n = min(X.shape[0], int(hp.num_first_datapoints_test))
             X, M, I = X[:n], M[:n], I[:n]

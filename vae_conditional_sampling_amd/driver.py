@@ -8,6 +8,15 @@ life-cycle of hooks around every batch.  ``test_class.class_path`` may name the 
 module (``irwg.sampling.test_step_vae_sampling.<Class>``); it is resolved to this package's class
 of the same name.
 
+Sharded runs (one process per GPU, ``world_size`` > 1): every rank samples a contiguous block of the
+test set with no collective in the loop and keeps its per-batch artefacts in memory; after the loop
+they are gathered in global example order (one all-gather per stored array), rank 0 cuts them into
+the batches of the one-process data loader and writes the same files a one-process run writes
+(``imputations_{b}.npz``, ``irwg_imputations_after_final_resampling_{b}.npz``,
+``metrics_summary.npz``, ``is_norm_log_weights.npz``) into one ``version_N`` directory chosen by
+rank 0.  Without a process group (ranks run one after another in one process, as the tests do) the
+gather is left to the caller: ``tester.collector.shard_arrays()`` + ``distributed.merge_shards``.
+
 Keys that exist only here:
   ``model_config``  YAML with the network architecture (the reference's *training* config, whose
                     ``model.init_args`` block is read); the reference stores it in the checkpoint.
@@ -22,6 +31,7 @@ import os
 import torch
 import yaml
 
+from . import distributed
 from .data import MissingDataModule
 from .models import VAE, ResidualFCNetwork, ResNetDecoder, ResNetEncoder
 from .sampling import test_step_vae_sampling
@@ -128,9 +138,8 @@ def run(cfg, *, device=None, rank=0, world_size=1):
     datamodule.set_model(model)
     tester.rng_seed = int(cfg["seed_everything"])
     tester.skip_unimplemented_diagnostics = bool(cfg.get("skip_unimplemented_diagnostics", False))
-    tester.out_dir = os.path.join(experiment_dir, "lightning_logs", f"version_{_next_version(experiment_dir)}")
-    if world_size > 1:
-        tester.out_dir = os.path.join(tester.out_dir, f"rank_{rank}")
+    sharded = world_size > 1
+    prepare_outputs(tester, experiment_dir, rank, sharded)
 
     datamodule.setup("test")
     tester.on_test_start()
@@ -145,8 +154,33 @@ def run(cfg, *, device=None, rank=0, world_size=1):
             tester.on_test_batch_end(out, batch, batch_idx, 0)
             outputs.append(out)
             offset += batch[0].shape[0]
-    tester.test_epoch_end(outputs)
+    finish_run(tester, outputs, datamodule.num_test_total, datamodule.hparams.batch_size, rank, sharded, device)
     return tester, outputs
+
+
+def prepare_outputs(tester, experiment_dir, rank, sharded):
+    """One ``version_N`` directory per run: rank 0 chooses it and tells the others before any rank
+    creates a directory; only rank 0 writes.  Sharded ranks keep their artefacts in a collector."""
+    version = _next_version(experiment_dir) if rank == 0 else None
+    if sharded:
+        version = distributed.broadcast_object(version)
+        tester.collector = distributed.ArtifactCollector()
+    tester.out_dir = (os.path.join(experiment_dir, "lightning_logs", f"version_{version}") if rank == 0 else None)
+    tester.run_version = version
+
+
+def finish_run(tester, outputs, num_test_total, batch_size, rank, sharded, device):
+    """End of the epoch.  Sharded with a process group: the only exchange of the path -- stored
+    imputations / final-resampling imputations / latents (one all-gather each, global example
+    order) and the per-batch metric records -- then rank 0 writes the files of a one-process run."""
+    if sharded and distributed.group_ready():
+        merged = distributed.gather_shard_arrays(tester.collector.shard_arrays(), num_test_total, device)
+        tester.metrics = distributed.gather_lists(dict(tester.metrics))
+        if getattr(tester, "norm_log_weights", None) is not None:
+            tester.norm_log_weights = distributed.gather_lists(list(tester.norm_log_weights))
+        if rank == 0:
+            distributed.write_batches(merged, batch_size, tester.out_dir, save=tester._write_npz)
+    tester.test_epoch_end(outputs)
 
 
 def _next_version(experiment_dir):

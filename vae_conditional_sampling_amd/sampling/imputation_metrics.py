@@ -15,12 +15,13 @@ from . import engine
 
 
 class PreparedTruth:
-    """The per-batch constants of the diagnostics, prepared once: X_true with NaNs zeroed [B,D], the
+    """The per-batch constants of the diagnostics, prepared once: X_true [B,D] as it is (a truth that is NaN
+    at missing entries, as in `nan_miss` data, gives NaN errors exactly as the reference's functions do), the
     mask as bytes [B,D], and (lazily) the posterior of the true data for the latent distance."""
 
     def __init__(self, X_true, M, like):
         B, K, D = like.shape
-        self.Xt = torch.nan_to_num(X_true.reshape(B, D).to(like.device, torch.float32)).contiguous()
+        self.Xt = X_true.reshape(B, D).to(like.device, torch.float32).contiguous()
         self.M8 = engine.mask_u8(M)
         self.q_true = None
 
@@ -68,7 +69,7 @@ def imputation_latent_wass(X_imp, X_true, vae, *, q_true=None, out=None):
     over the iterations of a batch, so the harness encodes it once."""
     B, K, D = X_imp.shape
     if q_true is None:
-        q_true = encode_posterior(vae, torch.nan_to_num(X_true.reshape(B, 1, D).to(X_imp.device, torch.float32)))
+        q_true = encode_posterior(vae, X_true.reshape(B, 1, D).to(X_imp.device, torch.float32))
     q_imp = encode_posterior(vae, X_imp)
     out = out if out is not None else torch.empty(B, K, device=X_imp.device, dtype=torch.float32)
     _lib.check(_lib.lib().cs_latent_wasserstein(_lib.ptr(q_imp), _lib.ptr(q_true), B, K, vae.latent_dim, _lib.ptr(out),

@@ -14,7 +14,9 @@ Extensions that do not exist in the reference (all optional):
   * ``draw_source``: an object with ``normal/uniform/uniform64/randint`` methods that supplies
     every random draw in the reference's call order (used by the parity tests to replay a tape
     recorded from the reference);
-  * ``out_dir``: where ``.npz`` artefacts go (the reference uses the Lightning logger's dir).
+  * ``out_dir``: where ``.npz`` artefacts go (the reference uses the Lightning logger's dir);
+  * ``collector``: when set (sharded runs), the per-batch artefacts are handed to it instead of being
+    written: the driver gathers them over the ranks and rank 0 writes the files of a one-process run.
 """
 import math
 import os
@@ -138,6 +140,7 @@ class TestVAESamplerBase(HyperparametersMixin):
         self.example_offset = 0
         self.draw_source = None
         self.out_dir = None
+        self.collector = None
         self.skip_unimplemented_diagnostics = False
         self._iteration = 0
 
@@ -166,8 +169,19 @@ class TestVAESamplerBase(HyperparametersMixin):
         self.metrics = defaultdict(list)
         self._writer = AsyncNpzWriter()
 
-    def _save_npz(self, path, **arrays):
-        """np.savez_compressed on a background thread (joined in test_epoch_end)."""
+    def _stores_artifacts(self):
+        return self.out_dir is not None or self.collector is not None
+
+    def _save_npz(self, name, **arrays):
+        """np.savez_compressed(out_dir/name) on a background thread (joined in test_epoch_end); with a
+        collector the arrays are kept for the gather over the ranks instead."""
+        if self.collector is not None:
+            self.collector.add(name, arrays)
+            return
+        os.makedirs(self.out_dir, exist_ok=True)
+        self._write_npz(os.path.join(self.out_dir, name), **arrays)
+
+    def _write_npz(self, path, **arrays):
         writer = getattr(self, "_writer", None)
         if writer is None:
             np.savez_compressed(path, **arrays)
@@ -318,9 +332,8 @@ class TestVAESamplerBase(HyperparametersMixin):
             imps = imps.astype(bool)
         lat = torch.stack(latents).cpu().numpy() if latents else []
         self.last_imputations = imps
-        if not hp.dont_store_imputations and self.out_dir is not None and self._harness_writes_imputations:
-            os.makedirs(self.out_dir, exist_ok=True)
-            self._save_npz(os.path.join(self.out_dir, f'imputations_{batch_idx}.npz'),
+        if not hp.dont_store_imputations and self._stores_artifacts() and self._harness_writes_imputations:
+            self._save_npz(f'imputations_{batch_idx}.npz',
                            imputations=imps, latents=lat, true_X=X_true1.cpu().numpy(),
                            masks=M.cpu().numpy(), data_idx=np.asarray(I.cpu() if torch.is_tensor(I) else I))
         out = {k: [float(v) for v in vals] for k, vals in metrics.items()}   # device scalars: read once, here
@@ -557,14 +570,12 @@ class TestVAELatentAdaptiveImportanceResampling(TestVAESamplerBase):
         dev = self.device
         M1 = M.to(dev).bool().unsqueeze(1)
         imps, Z, _ = self.final_resampling(X_true, M1)
-        bool_data = _check_if_bool(X_true.to(dev)[M.to(dev).bool()])
+        # float32 also for binary data: the reference decides its bool cast from the stored latents
+        # (test_step_vae_sampling.py:1988-1989, never 0/1), so this file always holds float32
         imps = imps.cpu().numpy()
-        if bool_data:
-            imps = imps.astype(bool)
         self.last_final_imputations = imps
-        if self.out_dir is not None:
-            os.makedirs(self.out_dir, exist_ok=True)
-            self._save_npz(os.path.join(self.out_dir, f'irwg_imputations_after_final_resampling_{batch_idx}.npz'),
+        if self._stores_artifacts():
+            self._save_npz(f'irwg_imputations_after_final_resampling_{batch_idx}.npz',
                            imputations=imps, latents=Z.cpu().numpy() if self.hparams.store_latents else [],
                            true_X=X_true.unsqueeze(1).cpu().numpy(), masks=M1.cpu().numpy(),
                            data_idx=np.asarray(I.cpu() if torch.is_tensor(I) else I))
@@ -662,9 +673,8 @@ class TestVAEImportanceResampling(TestVAESamplerBase):
         imps, _, _ = self.final_resampling(X_true, M1)
         imps = imps.cpu().numpy()
         self.last_final_imputations = imps
-        if self.out_dir is not None:
-            os.makedirs(self.out_dir, exist_ok=True)
-            self._save_npz(os.path.join(self.out_dir, f'imputations_{batch_idx}.npz'), imputations=imps,
+        if self._stores_artifacts():
+            self._save_npz(f'imputations_{batch_idx}.npz', imputations=imps,
                            true_X=X_true.unsqueeze(1).cpu().numpy(), masks=M1.cpu().numpy(),
                            data_idx=np.asarray(I.cpu() if torch.is_tensor(I) else I))
 

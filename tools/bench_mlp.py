@@ -64,8 +64,8 @@ def trace(B=65536):
     he, hd = model.var_latent_network.packed().handle, model.generator_network.packed().handle
     st = _lib.current_stream()
     rng = _lib.make_rng(1, 0, 0)
-    for name, fn, rows, npts in (("enc", lambda: L.cs_lair_encode(he, C.byref(cfg), C.byref(bufs), st), B * K, 10),
-                                 ("dec", lambda: L.cs_lair_decode(hd, C.byref(cfg), C.byref(bufs), C.byref(rng), st), B * (K + R), 7)):
+    for name, fn, rows, npts in (("enc", lambda: L.cs_lair_encode(he, C.byref(cfg), C.byref(bufs), st), B * K, int(os.environ.get("CS_TRACE_ENC_PTS", 10))),
+                                 ("dec", lambda: L.cs_lair_decode(hd, C.byref(cfg), C.byref(bufs), C.byref(rng), st), B * (K + R), int(os.environ.get("CS_TRACE_DEC_PTS", 7)))):
         fn(); torch.cuda.synchronize()
         tiles = (rows + 15) // 16
         buf = torch.zeros(tiles, 16, dtype=torch.int64, device="cuda")
@@ -81,6 +81,7 @@ def trace(B=65536):
               "total median", int(np.median(t[:, -1] - t[:, 0])))
         # occupancy time line per XCD (the tick counters of different XCDs are not aligned)
         raw = buf.cpu().numpy()
+        raw = raw[raw[:, 0] != 0]
         hw = raw[:, 15]
         xcc = (hw >> 32) & 0xF
         hwid = hw & 0xFFFFFFFF
@@ -102,9 +103,6 @@ def trace(B=65536):
                 edges = np.linspace(0, a1.max(), 21)
                 occ = [int(((a0 <= e) & (a1 > e)).sum()) for e in edges[:-1]]
                 print(f"  cu key {k_}: {sel.sum()} waves, span {a1.max():.0f} ticks, resident waves at 20 points: {occ}")
-                order = np.argsort(a0)
-                print("   starts:", (a0[order][::4] / 1e3).astype(int).tolist())
-                print("   ends:  ", (np.sort(a1)[::4] / 1e3).astype(int).tolist())
         spans, busy = np.array(spans), np.array(busy)
         print(f"  {len(spans)} CUs: span median {np.median(spans):.0f} min {spans.min():.0f} max {spans.max():.0f} ticks;",
               f"mean residency {busy.mean() * 8:.2f} of 8 wave slots; launch/span tick rate {np.median(spans) / (ms * 1e6):.3f} GHz")

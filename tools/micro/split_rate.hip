@@ -13,6 +13,9 @@
 //   3  + the weights streamed global -> LDS by LDS-DMA (2 k-steps per ring slot, one barrier per slot)
 //   4  as 3, two output tiles at a time so that consecutive matrix instructions use different accumulators
 //   5  as 3 on v_mfma_f32_16x16x32_bf16 (16 output tiles of 16 features x two 16-row halves per 32-wide k-step)
+//   6  as 3 with the weights staged through registers instead of LDS-DMA: global_load_dwordx4 four at a time,
+//      ds_write_b128 two output tiles later, spread over the slot's 16 tile groups
+//   7  as 3 with the LDS-DMA copies spread over the slot's tile groups (one per group) instead of issued together
 // Prints f32-equivalent TFLOP/s (2*rows*in*out per layer) for the whole chip.
 //   hipcc -O3 --offload-arch=gfx950 -o split_rate split_rate.hip && ./split_rate
 #include <hip/hip_runtime.h>
@@ -70,11 +73,18 @@ k(float* out, int layers, const u32x4* gsrc, unsigned gmask) {
 #pragma unroll
   for (int t = 0; t < 16; ++t) { acc4[t][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc4[t][1] = acc4[t][0]; }
   size_t gpos = (size_t)blockIdx.x * 977;
+  const u32x4* stg_src = gsrc;
+  u32x4 stg[4];
   for (int L = 0; L < layers; ++L) {
 #pragma unroll
     for (int ks = 0; ks < 16; ++ks) {
       const int slot = (ks >> 1) & 1;
-      if (V >= 3 && (ks & 1) == 0) {
+      if ((V == 6 || V == 7) && (ks & 1) == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        stg_src = gsrc + ((gpos * (SLOT_BYTES / 16)) & gmask) + threadIdx.x;
+        ++gpos;
+      } else if (V >= 3 && V <= 5 && (ks & 1) == 0) {
         // the slot that the previous pair of k-steps used is free after this barrier; fill it for the
         // pair after this one
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -132,6 +142,28 @@ k(float* out, int layers, const u32x4* gsrc, unsigned gmask) {
 #pragma unroll
       for (int t = 0; t < 8; ++t) {
         if (V >= 1) { a0 = wl[(t * 3 + 0) * 64]; a1 = wl[(t * 3 + 1) * 64]; a2 = wl[(t * 3 + 2) * 64]; }
+        if (V == 6) {
+          // group G = 8*(ks&1) + t of the slot: batches of 4 copies loaded at G = 0, 4, 8 and written at G = 3, 7, 11
+          const int G = 8 * (ks & 1) + t;
+          u32x4* dstb = lds + (slot ^ 1) * (SLOT_BYTES / 16) + threadIdx.x;
+          if (G == 0 || G == 4 || G == 8) {
+            const int c0 = G;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) stg[c] = __builtin_nontemporal_load(stg_src + (c0 + c) * 256);
+          }
+          if (G == 3 || G == 7 || G == 11) {
+            const int c0 = G - 3;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) dstb[(c0 + c) * 256] = stg[c];
+          }
+        }
+        if (V == 7) {
+          const int G = 8 * (ks & 1) + t;
+          if (G < 12)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(stg_src + G * 256),
+                                             (__attribute__((address_space(3))) void*)(lds + (slot ^ 1) * (SLOT_BYTES / 16) + G * 256 + wave * 64),
+                                             16, 0, 0);
+        }
         MFMA(a0, b0, acc[t]);
         MFMA(a0, b1, acc[t]);
         MFMA(a1, b0, acc[t]);
@@ -163,7 +195,18 @@ k(float* out, int layers, const u32x4* gsrc, unsigned gmask) {
 template <int V>
 void run(int blocks, int layers, size_t gbytes) {
   float* out; u32x4* gsrc;
-  hipMalloc(&gsrc, gbytes + SLOT_BYTES); hipMemset(gsrc, 0x3c, gbytes + SLOT_BYTES);
+  hipMalloc(&gsrc, gbytes + SLOT_BYTES);
+  {  // pseudo-random bf16 bit patterns of moderate exponent: the clock the chip holds depends on the data
+    const size_t nw = (gbytes + SLOT_BYTES) / 4;
+    unsigned* h = (unsigned*)malloc(nw * 4);
+    unsigned x = 12345u;
+    for (size_t i = 0; i < nw; ++i) {
+      x = x * 1664525u + 1013904223u;
+      h[i] = 0x3c003c00u | (x & 0x807f807fu) | ((x >> 9) & 0x03000300u);
+    }
+    hipMemcpy(gsrc, h, nw * 4, hipMemcpyHostToDevice);
+    free(h);
+  }
   hipMalloc(&out, (size_t)blocks * 256 * 4);
   hipFuncSetAttribute((const void*)k<V>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * SLOT_BYTES);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -194,5 +237,10 @@ int main(int argc, char** argv) {
   run<5>(blocks, layers, 4 << 20);
   run<3>(blocks, layers, 4 << 20);
   run<5>(blocks, layers, 4 << 20);
+  run<6>(blocks, layers, 4 << 20);
+  run<7>(blocks, layers, 4 << 20);
+  run<3>(blocks, layers, 4 << 20);
+  run<6>(blocks, layers, 4 << 20);
+  run<7>(blocks, layers, 4 << 20);
   return 0;
 }

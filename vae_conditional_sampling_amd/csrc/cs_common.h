@@ -23,13 +23,22 @@ __device__ __forceinline__ void cs_dma16(const void* sbase, unsigned lane_off, u
                : "memory", "m0");  // M0 is written: the compiler must not keep a value of its own in it across the copy
 }
 __device__ __forceinline__ unsigned cs_scalar_u32(unsigned v) { return __builtin_amdgcn_readfirstlane(v); }
-// Wait states between the last matrix instruction of a kernel's main loop and the first vector instruction
-// that reads its accumulators.  The compiler inserts them itself in straight-line code, but not across the
-// branch that follows the loop here: the epilogue then read the last-written accumulator registers a few
-// instructions after the matrix instruction was issued and, depending on the timing, saw them without its
-// contribution (found as run-to-run differences in the last bits of two output columns).
+// Wait states between the last matrix instruction of a kernel's main loop and the first instruction that
+// reads its accumulators.  The compiler pads its own code to the documented minimum counted from the ISSUE of
+// the matrix instruction (12 states for an 8-pass instruction).  Behind a run of back-to-back matrix
+// instructions issue runs ahead of execution, and that minimum proved too short: the disassembly of the build
+// that failed shows the output layer's last v_mfma followed, 12 states later, by v_accvgpr_read of the tile's
+// last register, and that register now and then lacked the final product (last bits of two output columns,
+// a few launches in a hundred).  64 further states follow the final matrix instruction of every matrix kernel;
+// the scheduling barriers on both sides keep every matrix instruction above and every reader below them
+// (an asm statement alone orders memory accesses, not register-only instructions).
+// tools/hazard_audit.py checks the distance in the shipped code objects (tests/test_hazard_audit.py).
 __device__ __forceinline__ void cs_mfma_drain() {
+#ifndef CS_NO_MFMA_DRAIN   // tools/hazard_audit.py can be pointed at a build without it: what the compiler emits alone
+  __builtin_amdgcn_sched_barrier(0);
   asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+#endif
 }
 #endif
 

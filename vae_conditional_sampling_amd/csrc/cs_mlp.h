@@ -21,6 +21,9 @@ struct CsMlpDev {
   const float* bias3;    // [2*nb+2][bias_stride3], final layer in 32-row tile order
   int nto3;              // output tiles of 32
   int bias_stride3;
+  // 16-row-tile split-bf16 variant (cs_mlp_split16_kernel.inc): the same three bf16 terms in 16-row tile order;
+  // bias table and output tile geometry are those of the exact-f32 kernel (bias, nto, tph)
+  const f32x4* wstream16;
 };
 
 struct CsProgram;
@@ -31,6 +34,7 @@ struct cs_mlp {
   void* d_b;
   void* d_w3;
   void* d_b3;
+  void* d_w16;
   int device;
   CsProgram* prog;  // layer-program networks (cs_net_create); null for the fused MLP
 };

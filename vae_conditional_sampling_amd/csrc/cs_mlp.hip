@@ -22,6 +22,23 @@ int cs_mlp_launch_h256(const CsMlpArgs& a, hipStream_t stream);
 int cs_mlp_split_launch_h64(const CsMlpArgs& a, hipStream_t stream);
 int cs_mlp_split_launch_h128(const CsMlpArgs& a, hipStream_t stream);
 int cs_mlp_split_launch_h256(const CsMlpArgs& a, hipStream_t stream);
+int cs_mlp_split16_launch_h64(const CsMlpArgs& a, hipStream_t stream, int waves);
+int cs_mlp_split16_launch_h128(const CsMlpArgs& a, hipStream_t stream, int waves);
+int cs_mlp_split16_launch_h256(const CsMlpArgs& a, hipStream_t stream, int waves);
+
+// Row tile of the split-bf16 arithmetic: 32 (cs_mlp_split_kernel.inc, one wave per SIMD) or 16
+// (cs_mlp_split16_kernel.inc, two waves per SIMD / half the dependent chain per row tile).
+// CSVAE_SPLIT_TILE = 32 | 16 | auto (default): auto takes the 16-row kernel for launches too small to fill the
+// chip with 32-row tiles (the time of a small batch is the dependent chain of one row tile through the network)
+// and the 32-row kernel otherwise.  CSVAE_SPLIT16_WAVES = 4 | 8 overrides the workgroup width of the 16-row kernel.
+static int g_split_tile = -1, g_split16_waves = -1;
+static void cs_split_cfg() {
+  if (g_split_tile >= 0) return;
+  const char* e = std::getenv("CSVAE_SPLIT_TILE");
+  g_split_tile = (e && std::strcmp(e, "16") == 0) ? 16 : (e && std::strcmp(e, "32") == 0) ? 32 : 0;
+  const char* w = std::getenv("CSVAE_SPLIT16_WAVES");
+  g_split16_waves = (w && std::strcmp(w, "4") == 0) ? 4 : (w && std::strcmp(w, "8") == 0) ? 8 : 0;
+}
 
 // Arithmetic of the fused-MLP matrix products: the f32-equivalent 3-way bf16 split (6 bf16 matrix
 // instructions per product, cs_mlp_split_kernel.inc; the default: measured as accurate against a
@@ -57,7 +74,12 @@ int cs_mlp_launch(const CsMlpArgs& a_in, hipStream_t stream) {
   a.dbg = g_trace;
   if (a.rows <= 0) return CS_OK;
   if (a.net.prog) return cs_prog_launch(a, stream);
-  if (a.mode == CS_MLP_DEC && a.in == nullptr && (a.latent_dist == CS_DIST_BETA || cs_mlp_arith() == CS_ARITH_BF16X3)) {
+  cs_split_cfg();
+  // 32-row tiles fill 256 CUs x 4 waves from 32 768 rows on; below a quarter of that the 16-row kernel's shorter
+  // chain wins
+  const bool tile16 = cs_mlp_arith() == CS_ARITH_BF16X3 && (g_split_tile == 16 || (g_split_tile == 0 && a.rows <= 8192));
+  if (a.mode == CS_MLP_DEC && a.in == nullptr &&
+      (a.latent_dist == CS_DIST_BETA || (cs_mlp_arith() == CS_ARITH_BF16X3 && !tile16))) {
     // Beta proposals are drawn by a kernel of their own; the fused kernel then reads Z as its input.
     // The split-bf16 kernel runs one wavefront per SIMD, so nothing would cover the counter-RNG work of
     // its prologue: there too the proposals are drawn by the full-occupancy kernel first.
@@ -70,6 +92,15 @@ int cs_mlp_launch(const CsMlpArgs& a_in, hipStream_t stream) {
   if (a.mode == CS_MLP_ENC) CS_REQUIRE(a.net.split == 2, "encoder output must be (loc | scale)");
   if (a.mode == CS_MLP_DEC && a.gen_dist != CS_DIST_BERN)
     CS_REQUIRE(a.net.split == 2, "generator output must be (loc | scale)");
+  if (tile16) {
+    // 8-wave workgroups (two waves per SIMD) once there are enough row tiles for every CU, else 4-wave ones
+    const int waves = g_split16_waves ? g_split16_waves : ((a.rows + 127) / 128 >= 256 ? 8 : 4);
+    switch (a.net.nt) {
+      case 4: return cs_mlp_split16_launch_h64(a, stream, waves);
+      case 8: return cs_mlp_split16_launch_h128(a, stream, waves);
+      case 16: return cs_mlp_split16_launch_h256(a, stream, waves);
+    }
+  }
   if (cs_mlp_arith() == CS_ARITH_BF16X3) {
     switch (a.net.nt) {
       case 4: return cs_mlp_split_launch_h64(a, stream);
@@ -142,6 +173,29 @@ void pack_layer3(std::vector<uint16_t>& s, const float* W, int k_real, int kt_co
               s.push_back(p == 0 ? t0 : (p == 1 ? t1 : t2));
             }
           }
+}
+// 16-row-tile split-bf16 operand stream of one layer: per k-step of 32 features, per 16-row output tile, per
+// term p of the 3-way split, per lane (m = lane&15, g = lane>>4), the 8 columns
+// k = 32s + 16(j>>2) + 4g + (j&3) of row tile_row(t, m) (-1 = padding): k-slot 8g + j of the matrix instruction
+// carries the feature that a lane of group g holds in register j&3 of tile 2s + (j>>2) of the previous layer.
+template <class RowFn>
+void pack_layer16(std::vector<uint16_t>& s, const float* W, int k_real, int ks_count, int ntiles, RowFn tile_row) {
+  for (int ks = 0; ks < ks_count; ++ks)
+    for (int t = 0; t < ntiles; ++t)
+      for (int p = 0; p < 3; ++p)
+        for (int lane = 0; lane < 64; ++lane) {
+          const int m = lane & 15, g = lane >> 4;
+          const int n = tile_row(t, m);
+          for (int j = 0; j < 8; ++j) {
+            const int k = 32 * ks + 16 * (j >> 2) + 4 * g + (j & 3);
+            const float v = (n >= 0 && k < k_real) ? W[(size_t)n * k_real + k] : 0.0f;
+            const uint16_t t0 = bf16_rne(v);
+            const float r1 = v - bf16_val(t0);
+            const uint16_t t1 = bf16_rne(r1);
+            const uint16_t t2 = bf16_rne(r1 - bf16_val(t1));
+            s.push_back(p == 0 ? t0 : (p == 1 ? t1 : t2));
+          }
+        }
 }
 }  // namespace
 
@@ -220,8 +274,17 @@ extern "C" int cs_mlp_create(const cs_mlp_desc* d, const float* W0, const float*
       if (n >= 0) bias3[(size_t)(nl - 1) * bst3 + 32 * t + i] = bf[n];
     }
 
+  // 16-row-tile split variant: the tile geometry (hid_row / out_row, nto, bias table) of the exact-f32 kernel
+  std::vector<uint16_t> s16;
+  pack_layer16(s16, W0, d->in_dim, nkt0, NT, hid_row);
+  for (int b = 0; b < nb; ++b)
+    for (int l = 0; l < 2; ++l) pack_layer16(s16, Wblk + ((size_t)b * 2 + l) * H * H, H, NKT, NT, hid_row);
+  pack_layer16(s16, Wf, H, NKT, nto, out_row);
+  s16.resize(s16.size() + ((size_t)2 * (NT > nto ? NT : nto) * 3 * 64 + 1024) * 8, 0);  // trailing prefetch: a rounded slot
+
   cs_mlp* m = new cs_mlp();
   m->desc = *d;
+  m->d_w16 = nullptr;
   m->d_w = nullptr;
   m->d_b = nullptr;
   m->d_w3 = nullptr;
@@ -236,7 +299,10 @@ extern "C" int cs_mlp_create(const cs_mlp_desc* d, const float* W0, const float*
   if (e == hipSuccess) e = hipMalloc(&m->d_b3, bias3.size() * sizeof(float));
   if (e == hipSuccess) e = hipMemcpy(m->d_w3, s3.data(), s3.size() * sizeof(uint16_t), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(m->d_b3, bias3.data(), bias3.size() * sizeof(float), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMalloc(&m->d_w16, s16.size() * sizeof(uint16_t));
+  if (e == hipSuccess) e = hipMemcpy(m->d_w16, s16.data(), s16.size() * sizeof(uint16_t), hipMemcpyHostToDevice);
   if (e != hipSuccess) {
+    if (m->d_w16) (void)hipFree(m->d_w16);
     if (m->d_w) (void)hipFree(m->d_w);
     if (m->d_b) (void)hipFree(m->d_b);
     if (m->d_w3) (void)hipFree(m->d_w3);
@@ -261,6 +327,7 @@ extern "C" int cs_mlp_create(const cs_mlp_desc* d, const float* W0, const float*
   m->dev.bias3 = (const float*)m->d_b3;
   m->dev.nto3 = nto3;
   m->dev.bias_stride3 = bst3;
+  m->dev.wstream16 = (const f32x4*)m->d_w16;
   *out = m;
   return CS_OK;
 }
@@ -272,6 +339,7 @@ extern "C" int cs_mlp_destroy(cs_mlp_t* m) {
   if (m->d_b) (void)hipFree(m->d_b);
   if (m->d_w3) (void)hipFree(m->d_w3);
   if (m->d_b3) (void)hipFree(m->d_b3);
+  if (m->d_w16) (void)hipFree(m->d_w16);
   delete m;
   return CS_OK;
 }

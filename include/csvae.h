@@ -225,6 +225,23 @@ int cs_lair_resample_impute(const cs_lair_cfg* cfg, const cs_lair_bufs* b, const
 int cs_lair_step(const cs_mlp_t* enc, const cs_mlp_t* dec, const cs_lair_cfg* cfg, const cs_lair_bufs* b,
                  const cs_rng* rng, void* stream);
 
+/* T LAIR iterations in one call: the loop of TestVAELatentAdaptiveImportanceResampling.sampler
+ * (test_step_vae_sampling.py:1887-1962) for callers that need nothing on the host between iterations.
+ * Iteration t is exactly cs_lair_step with rng->iteration + t.  With `out`, iteration t writes its proposals
+ * and log-weights into block t of Z_store[T,I,B,K',Zd] / log_w_store[T,I,B,K'] (the proposals the reference
+ * collects for the final resampling, :1938-1940) and its statistics into row t of ess_store / tess_store /
+ * perplexity_store [T,B]; a NULL store leaves the corresponding buffer of `b` in use (overwritten every
+ * iteration).  Injected draws in `b`, when not NULL, hold T consecutive blocks of their per-iteration shapes. */
+typedef struct {
+  float* Z_store;
+  float* log_w_store;
+  float* ess_store;
+  float* tess_store;
+  float* perplexity_store;
+} cs_lair_run_out;
+int cs_lair_run(const cs_mlp_t* enc, const cs_mlp_t* dec, const cs_lair_cfg* cfg, const cs_lair_bufs* b,
+                const cs_rng* rng, int32_t T, const cs_lair_run_out* out, void* stream);
+
 /* ---------------------------------------------------------------------------------------
  * AC-MWG (test_step_vae_sampling.py:1512-1768).  The imputation history
  * (ImputationHistoryQueue_with_restrictedavailability, irwg/sampling/utils.py:83-237) is a

@@ -140,3 +140,46 @@ def test_sharded_driver_runs_reassemble_the_one_process_artifacts(tmp_path, conf
         assert sorted(a.files) == sorted(b.files)
         for k in a.files:
             assert a[k].dtype == b[k].dtype and np.array_equal(a[k], b[k]), f"{name}[{k}] differs between the runs"
+
+
+def test_sampler_runs_unobserved_stretches_in_one_call_with_identical_results(tmp_path):
+    """With only the last iterations stored and no per-iteration diagnostics the LAIR sampler runs the stretches
+    in between through cs_lair_run; stored imputations, final-resampling imputations and the ESS series must equal
+    those of the step-by-step run (bit for bit for the chain, to rounding for the batch means)."""
+    from vae_conditional_sampling_amd import driver
+    from vae_conditional_sampling_amd.sampling import test_step_vae_sampling as TS
+    over = ["data.synthetic_num_test=150", "data.num_first_datapoints_test=70", "data.batch_size=64",
+            "test_class.init_args.num_iterations=23", "test_class.init_args.store_last_n_iterations=2",
+            "test_class.init_args.compute_rmse_metric=False", "test_class.init_args.compute_mae_metric=False",
+            "test_class.init_args.compute_latent_wass_metric=False"]
+    res = []
+    calls = []
+    orig_run = TS.engine.lair_run
+    for cap in (1, 8):
+        cfg = driver.load_config(os.path.join(ROOT, "configs/uci_miniboone/sampling_u50/lair_k4_dmis_gr_mult_1replenish.yaml"),
+                                 over + [f"trainer.default_root_dir={tmp_path / str(cap)}"])
+        TS.engine.lair_run = lambda *a, **k: (calls.append((cap, a[5])), orig_run(*a, **k))[1]
+        old_init = TS.TestVAESamplerBase.on_test_start
+
+        def patched(self, _cap=cap, _old=old_init):
+            _old(self)
+            self.max_iterations_per_call = _cap
+        TS.TestVAESamplerBase.on_test_start = patched
+        try:
+            tester, outs = driver.run(cfg)
+        finally:
+            TS.TestVAESamplerBase.on_test_start = old_init
+            TS.engine.lair_run = orig_run
+        files = {n: dict(np.load(os.path.join(tester.out_dir, n))) for n in sorted(os.listdir(tester.out_dir)) if n.endswith(".npz")}
+        res.append((files, outs))
+    assert not [c for c in calls if c[0] == 1] and [c[1] for c in calls if c[0] == 8][:3] == [8, 8, 6]   # 21 unread states, each call ends at most at the first state that is read
+    (f1, o1), (f8, o8) = res
+    assert sorted(f1) == sorted(f8) and "irwg_imputations_after_final_resampling_1.npz" in f1
+    for n in f1:
+        for k in f1[n]:
+            if n == "metrics_summary.npz":
+                np.testing.assert_allclose(f1[n][k], f8[n][k], rtol=1e-6)
+            else:
+                assert np.array_equal(f1[n][k], f8[n][k]), f"{n}[{k}] differs"
+    assert f1["imputations_0.npz"]["imputations"].shape == (3, 64, 4, 43)
+    np.testing.assert_allclose(o1[0]["is_ess"], o8[0]["is_ess"], rtol=1e-6)

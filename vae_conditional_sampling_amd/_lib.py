@@ -79,6 +79,10 @@ class cs_lair_bufs(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in _LAIR_BUF_FIELDS]
 
 
+class cs_lair_run_out(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("Z_store", "log_w_store", "ess_store", "tess_store", "perplexity_store")]
+
+
 class cs_acmwg_cfg(C.Structure):
     _fields_ = [("B", C.c_int32), ("K", C.c_int32), ("D", C.c_int32), ("Zd", C.c_int32),
                 ("latent_dist", C.c_int32), ("gen_dist", C.c_int32), ("hist_len", C.c_int32),
@@ -130,6 +134,8 @@ def lib():
     L.cs_lair_decode.argtypes = [vp, C.POINTER(cs_lair_cfg), C.POINTER(cs_lair_bufs), C.POINTER(cs_rng), vp]
     L.cs_lair_resample_impute.argtypes = [C.POINTER(cs_lair_cfg), C.POINTER(cs_lair_bufs), C.POINTER(cs_rng), vp]
     L.cs_lair_step.argtypes = [vp, vp, C.POINTER(cs_lair_cfg), C.POINTER(cs_lair_bufs), C.POINTER(cs_rng), vp]
+    L.cs_lair_run.argtypes = [vp, vp, C.POINTER(cs_lair_cfg), C.POINTER(cs_lair_bufs), C.POINTER(cs_rng), i32,
+                              C.POINTER(cs_lair_run_out), vp]
     L.cs_acmwg_init_state.argtypes = [vp, vp, C.POINTER(cs_acmwg_cfg), C.POINTER(cs_acmwg_bufs), C.POINTER(cs_rng), vp]
     L.cs_acmwg_step.argtypes = [vp, vp, C.POINTER(cs_acmwg_cfg), C.POINTER(cs_acmwg_bufs), C.POINTER(cs_rng), vp]
     L.cs_history_concat.argtypes = [vp, vp, i64, i32, i32, i32, C.POINTER(i32), C.POINTER(i32), vp,

@@ -896,6 +896,51 @@ extern "C" int cs_sample_impute(const float* gen, int32_t gen_dist, const float*
 }
 
 // ----------------------------------------------------------------------------------------
+// T LAIR iterations in one call: the loop `for t in range(num_iterations)` of
+// TestVAELatentAdaptiveImportanceResampling.sampler (test_step_vae_sampling.py:1887-1962) for callers that need
+// no host-side work between the iterations.  Iteration t runs exactly cs_lair_step with rng.iteration + t; its
+// proposals and log-weights go straight into the t-th block of the stores when those are given (the proposals
+// kept for the final resampling, :1938-1940), its statistics into the t-th row of the statistics stores.
+// Injected draws, when given, hold T consecutive blocks of the per-iteration shapes.
+// ----------------------------------------------------------------------------------------
+extern "C" int cs_lair_run(const cs_mlp_t* enc, const cs_mlp_t* dec, const cs_lair_cfg* c, const cs_lair_bufs* b0,
+                           const cs_rng* rng, int32_t T, const cs_lair_run_out* out, void* stream) {
+  CS_REQUIRE(c && b0 && T >= 0, "bad argument");
+  if (int rc = check_cfg(c, b0)) return rc;
+  const int64_t B = c->B, Kp = c->K + c->R, I = c->I, Zd = c->Zd;
+  const int64_t Kimp = c->K_impute > 0 ? c->K_impute : c->K;
+  const int64_t Kg = c->glr_pad_to > 0 && c->scheme == CS_RS_GLR ? c->glr_pad_to : Kp;
+  // per-iteration element counts of the injected draws (layouts of cs_lair_bufs)
+  const int64_t n_eps_z = I * B * Kp * Zd, n_eps_x = B * Kimp * c->D;
+  const int64_t n_u_res = B * Kg;                                                      // multinomial gr / glr
+  const int64_t n_u_sys = c->scheme == CS_RS_GR ? B : (c->scheme == CS_RS_GLR ? B * (Kg / (c->cluster_size > 0 ? c->cluster_size : 1)) : B * Kp);
+  const int64_t n_e_res = B * Kp * I;                                                  // lr / ir, multinomial
+  cs_rng r = rng ? *rng : cs_rng{0, 0, 0};
+  for (int32_t t = 0; t < T; ++t) {
+    cs_lair_bufs b = *b0;
+    if (b.eps_z) b.eps_z += t * n_eps_z;
+    if (b.eps_x) b.eps_x += t * n_eps_x;
+    if (b.u_res) b.u_res += t * n_u_res;
+    if (b.u_res2) b.u_res2 += t * n_u_res;
+    if (b.u_sys) b.u_sys += t * n_u_sys;
+    if (b.u_sys2) b.u_sys2 += t * n_u_sys;
+    if (b.e_res) b.e_res += t * n_e_res;
+    if (b.e_res2) b.e_res2 += t * n_e_res;
+    if (out) {
+      if (out->Z_store) b.Z = out->Z_store + t * I * B * Kp * Zd;
+      if (out->log_w_store) b.log_w = out->log_w_store + t * I * B * Kp;
+      if (out->ess_store) b.ess = out->ess_store + t * B;
+      if (out->tess_store) b.tess = out->tess_store + t * B;
+      if (out->perplexity_store) b.perplexity = out->perplexity_store + t * B;
+    }
+    cs_rng rt = r;
+    rt.iteration = r.iteration + (uint32_t)t;
+    if (int rc = cs_lair_step(enc, dec, c, &b, &rt, stream)) return rc;
+  }
+  return CS_OK;
+}
+
+// ----------------------------------------------------------------------------------------
 // LAIR final resampling (test_step_vae_sampling.py:1998-2009): per example a Categorical over
 // all S = T*I*K' stored proposals, n draws, gather of the chosen latents.
 // One wavefront per example.  The CDF is the float32 running sum in index order divided by the

@@ -71,10 +71,9 @@ def lair_cfg(model, ws, *, weighting, scheme, method, cluster_size, weight_alpha
                             model.engine_prior(), temp, anneal)
 
 
-def lair_step(model, ws, X, M8, cfg, *, rng=None, draws=None, return_resampled_latents=False,
-              clip_min=None, clip_max=None, prior_proposals=False, X_out=None):
-    """One LAIR iteration in place on ``X`` [B,K,D] (cs_lair_step).  ``prior_proposals``: every
-    chain proposes from the prior instead of the encoder (standard importance resampling)."""
+def _lair_bufs(ws, X, M8, cfg, draws, return_resampled_latents, clip_min, clip_max, X_out):
+    """cs_lair_bufs of one iteration (or, with draws stacked along a leading T axis, of cs_lair_run); the second
+    value keeps the converted draw tensors alive."""
     draws = draws or {}
     dev = X.device
     g = lambda k, dt: (draws[k].to(dev, dt).contiguous() if draws.get(k) is not None else None)
@@ -98,6 +97,14 @@ def lair_step(model, ws, X, M8, cfg, *, rng=None, draws=None, return_resampled_l
                           latents_resampled=ws.latents_resampled if return_resampled_latents else None,
                           idx2=ws.idx2 if return_resampled_latents else None,
                           clip_min=clip_min, clip_max=clip_max, X_out=X_out, **ud)
+    return bufs, keep
+
+
+def lair_step(model, ws, X, M8, cfg, *, rng=None, draws=None, return_resampled_latents=False,
+              clip_min=None, clip_max=None, prior_proposals=False, X_out=None):
+    """One LAIR iteration in place on ``X`` [B,K,D] (cs_lair_step).  ``prior_proposals``: every
+    chain proposes from the prior instead of the encoder (standard importance resampling)."""
+    bufs, keep = _lair_bufs(ws, X, M8, cfg, draws, return_resampled_latents, clip_min, clip_max, X_out)
     rng = rng if rng is not None else _lib.make_rng(0)
     dec = model.generator_network.packed()
     L, st = _lib.lib(), _lib.current_stream()
@@ -108,6 +115,22 @@ def lair_step(model, ws, X, M8, cfg, *, rng=None, draws=None, return_resampled_l
         return ws
     enc = model.var_latent_network.packed()
     _lib.check(L.cs_lair_step(enc.handle, dec.handle, C.byref(cfg), C.byref(bufs), C.byref(rng), st))
+    return ws
+
+
+def lair_run(model, ws, X, M8, cfg, T, *, rng=None, draws=None, Z_store=None, log_w_store=None, stats_store=None,
+             clip_min=None, clip_max=None):
+    """``T`` LAIR iterations in place on ``X`` [B,K,D] in one library call (cs_lair_run): iteration t is
+    ``lair_step`` with ``rng.iteration + t``.  ``draws``: the injected draws of all iterations stacked along a
+    leading T axis.  ``Z_store`` [T,I,B,K',Zd] / ``log_w_store`` [T,I,B,K'] receive every iteration's proposals and
+    log-weights, ``stats_store`` [3,T,B] its ESS, transformed ESS and perplexity."""
+    bufs, keep = _lair_bufs(ws, X, M8, cfg, draws, False, clip_min, clip_max, None)
+    rng = rng if rng is not None else _lib.make_rng(0)
+    out = _lib.cs_lair_run_out(_lib.ptr(Z_store), _lib.ptr(log_w_store),
+                               *(_lib.ptr(stats_store[i]) if stats_store is not None else None for i in range(3)))
+    enc, dec = model.var_latent_network.packed(), model.generator_network.packed()
+    _lib.check(_lib.lib().cs_lair_run(enc.handle, dec.handle, C.byref(cfg), C.byref(bufs), C.byref(rng), int(T),
+                                      C.byref(out), _lib.current_stream()))
     return ws
 
 

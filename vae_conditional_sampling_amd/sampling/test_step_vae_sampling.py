@@ -143,6 +143,10 @@ class TestVAESamplerBase(HyperparametersMixin):
         self.collector = None
         self.skip_unimplemented_diagnostics = False
         self._iteration = 0
+        # engine-side: a predicate t -> bool telling the sampler at which iterations the consumer looks at the chain
+        # state (None: at every one).  A sampler may run the iterations in between in one library call.
+        self._state_needed = None
+        self.max_iterations_per_call = 64
 
     # ---- wiring -------------------------------------------------------------------------
     def set_model(self, model):
@@ -305,6 +309,14 @@ class TestVAESamplerBase(HyperparametersMixin):
         imputations.append(X.clone())
         t = -1
         outputs = None
+
+        def stored(t_):
+            return ((hp.store_last_n_iterations == -1 or (self.max_iterations - hp.store_last_n_iterations) <= t_)
+                    and t_ % hp.store_every_n_iterations == 0)
+        # the chain state is read at iteration t when a diagnostic is computed from it, when it is stored, and at
+        # the end; a sampler may run the stretches in between without coming back to the host
+        last = self.max_iterations - 1
+        self._state_needed = (lambda t_: True) if point else (lambda t_: stored(t_) or t_ >= last)
         for t, outputs in enumerate(self.sampler(X, M)):
             X = outputs['X']
             if 'rmse' in point or 'mae' in point:  # one launch for both
@@ -326,6 +338,7 @@ class TestVAESamplerBase(HyperparametersMixin):
             imputations.append(X.clone())
             if hp.store_latents:
                 latents.append(outputs['Z'].clone())
+        self._state_needed = None
         # one device->host transfer for the whole sequence
         imps = torch.stack(imputations).cpu().numpy()
         if bool_data:
@@ -507,7 +520,39 @@ class TestVAELatentAdaptiveImportanceResampling(TestVAESamplerBase):
 
         all_norm_log_weights = []
         T = hp.num_iterations
-        for t in range(T):
+        # Stretches of iterations whose state nobody reads run in one library call (cs_lair_run): same kernels,
+        # same counter-RNG iteration numbers, so the chain is bit for bit the one of single steps.
+        can_run = (self._state_needed is not None and self.draw_source is None and history is None
+                   and not hp.store_latents and hp.weight_transform is None and not hp.store_norm_log_weights
+                   and hp.prior_replenish_iteration_frequency == 1 and self.max_iterations_per_call > 1)
+        t = 0
+        while can_run and t < T:
+            n = 1
+            while t + n < T and n < self.max_iterations_per_call and not self._state_needed(hp.num_pseudo_warmup_iterations + t + n - 1):
+                n += 1
+            if n == 1:
+                break   # the consumer reads every state from here on (or the stretch is over): single steps below
+            R = hp.num_prior_replenish_proposals
+            ws = engine.lair_workspace(self.model, B, K, R, hp.num_imp_samples, X.device)
+            cfg = engine.lair_cfg(self.model, ws, weighting=hp.weighting_scheme, scheme=hp.resampling_scheme,
+                                  method=hp.resampling_method, cluster_size=hp.glr_cluster_size, weight_alpha=None,
+                                  temperature=hp.var_proposal_temperature, anneal_type=hp.var_proposal_anneal_type_to_prior)
+            if hp.resample_final_imps and self._proposals is None:
+                self._proposals = (torch.empty((T,) + tuple(ws.Z.shape), device=X.device),
+                                   torch.empty((T,) + tuple(ws.log_w.shape), device=X.device))
+            stats = torch.empty(3, n, B, device=X.device)
+            engine.lair_run(self.model, ws, X, engine.mask_u8(M), cfg, n, rng=self._rng(),
+                            Z_store=self._proposals[0][t:t + n] if hp.resample_final_imps else None,
+                            log_w_store=self._proposals[1][t:t + n] if hp.resample_final_imps else None,
+                            stats_store=stats, clip_min=clip_min, clip_max=clip_max)
+            self._iteration += n
+            means = stats.mean(dim=2)   # [3, n]
+            for i in range(n):
+                yield {'X': X, 'Z': None, 'is_ess': means[0, i], 'is_ess_not_reduced': stats[0, i],
+                       'transformed_ess': means[1, i], 'perplexity': means[2, i],
+                       'total_num_props': hp.num_imp_samples * (K + R), 'acceptance_x': 1.0}
+            t += n
+        for t in range(t, T):
             weight_transform = None
             if hp.weight_transform == 'poly':
                 weight_transform = min((t + 10) / self.max_iterations, 1)

@@ -271,6 +271,39 @@ def leg_lair_class(model, B, K, R, D, T, dev, flops_per_example, arith, binary=F
                                                        "frac": tf / peak_of(arith), "what": "whole iteration (all kernels + host)"}}
 
 
+def leg_lair_run(model, B, K, R, D, T, dev, flops_per_example, arith, per_call=64):
+    """LAIR through cs_lair_run: `per_call` iterations per library call, proposals and statistics of every
+    iteration written into device stores (what the sampler class does for the iterations whose state nobody
+    reads).  This is the latency-bound regime of the reference's own batch size."""
+    from vae_conditional_sampling_amd import _lib
+    from vae_conditional_sampling_amd.sampling import engine
+    X, M = synthetic_batch(B, K, D, SEED + 7, dev)
+    M8 = M.to(torch.uint8).to(dev).contiguous()
+    ws = engine.lair_workspace(model, B, K, R, 1, dev)
+    cfg = engine.lair_cfg(model, ws, weighting="dmis", scheme="gr", method="multinomial", cluster_size=0, weight_alpha=None)
+    Zs = torch.empty((T,) + tuple(ws.Z.shape), device=dev)
+    lw = torch.empty((T,) + tuple(ws.log_w.shape), device=dev)
+    st = torch.empty(3, T, B, device=dev)
+
+    def run(t0, n):
+        engine.lair_run(model, ws, X, M8, cfg, n, rng=_lib.make_rng(SEED, t0, 0), Z_store=Zs[t0:t0 + n],
+                        log_w_store=lw[t0:t0 + n], stats_store=st[:, t0:t0 + n])
+    run(0, per_call)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for c in range(per_call, T, per_call):
+        run(c, min(per_call, T - c))
+    torch.cuda.synchronize()
+    sec = (time.perf_counter() - t0) / (T - per_call)
+    assert torch.isfinite(X).all()
+    tf = B * flops_per_example / sec / 1e12
+    return {"ms_per_step": sec * 1e3, "value": B * K / sec, "unit": "samples/s", "examples": B, "K": K, "R": R,
+            "iterations_timed": T - per_call, "iterations_per_call": per_call,
+            "roofline": {"bound": "latency", "achieved": tf, "peak": peak_of(arith), "unit": "TFLOP/s", "frac": tf / peak_of(arith),
+                         "what": "whole iteration; 2048 / 2560 network rows per launch occupy 32 / 40 of 256 CUs: the time is "
+                                 "the dependent chain of one 16-row tile through the networks"}}
+
+
 def leg_acmwg_class(model, B, K, D, T, dev, flops_per_chain, arith, binary=False, quadrants=False):
     """AC-MWG steps through TestVAEAdaptiveCollapsedMetropolisWithinGibbs.sampler (no warm-up, prior mixture
     probability 0.05, restricted-availability history on the device), counter RNG."""
@@ -315,6 +348,7 @@ def extra_legs(args, arith, dev):
     # LAIR MiniBooNE through the sampler class: at the large batch, and at the reference configuration's batch
     legs["lair_miniboone_sampler_class"] = leg_lair_class(model, args.batch, 4, 1, 43, 40, dev, 4 * f_enc + 5 * f_dec, arith)
     legs["lair_miniboone_sampler_class_b512"] = leg_lair_class(model, 512, 4, 1, 43, 300, dev, 4 * f_enc + 5 * f_dec, arith)
+    legs["latency_b512"] = leg_lair_run(model, 512, 4, 1, 43, 640, dev, 4 * f_enc + 5 * f_dec, arith)
     legs["acmwg_miniboone"] = leg_acmwg_class(model, args.batch, 5, 43, 40, dev, f_enc + f_dec, arith)
     del model
     torch.cuda.empty_cache()

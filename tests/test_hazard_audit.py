@@ -27,7 +27,7 @@ def test_no_matrix_result_is_consumed_early(tmp_path):
     report = json.loads(out.read_text())
     names = " ".join(r["kernel"] for r in report)
     # every family of matrix kernels was seen (a silent parse failure would make the audit vacuous)
-    for family in ("cs_mlp_split_kernel", "cs_mlp_kernel", "cs_conv3x3_halo_split_kernel", "cs_conv_mfma_split_kernel",
+    for family in ("cs_mlp_split16_kernel", "cs_mlp_split_kernel", "cs_mlp_kernel", "cs_conv3x3_halo_split_kernel", "cs_conv_mfma_split_kernel",
                    "cs_conv3x3_halo_kernel", "cs_conv_mfma_kernel"):
         assert family in names, f"no kernel of {family} in the audit"
     assert sum(r["mfma"] for r in report) > 20000

@@ -28,9 +28,12 @@ int cs_mlp_split16_launch_h256(const CsMlpArgs& a, hipStream_t stream, int waves
 
 // Row tile of the split-bf16 arithmetic: 32 (cs_mlp_split_kernel.inc, one wave per SIMD) or 16
 // (cs_mlp_split16_kernel.inc, two waves per SIMD / half the dependent chain per row tile).
-// CSVAE_SPLIT_TILE = 32 | 16 | auto (default): auto takes the 16-row kernel for launches too small to fill the
-// chip with 32-row tiles (the time of a small batch is the dependent chain of one row tile through the network)
-// and the 32-row kernel otherwise.  CSVAE_SPLIT16_WAVES = 4 | 8 overrides the workgroup width of the 16-row kernel.
+// CSVAE_SPLIT_TILE = 32 | 16 | auto (default): auto takes the 16-row kernel whenever its three-slot ring fits the
+// LDS (measured faster at every batch size, MiniBooNE shape, one LAIR step: 0.189 vs 0.243 ms at 512 examples --
+// the time of a small batch is the dependent chain of one row tile through the network, half as long with 16
+// rows -- and 2.37 vs 2.52 ms at 65 536: tools/sweep_tile.py), in 4-wave workgroups of 64 rows up to 20 480 rows
+// (320 workgroups) and 8-wave workgroups, two waves per SIMD, above.  CSVAE_SPLIT16_WAVES = 4 | 8 overrides the
+// workgroup width.
 static int g_split_tile = -1, g_split16_waves = -1;
 static void cs_split_cfg() {
   if (g_split_tile >= 0) return;
@@ -69,15 +72,22 @@ extern "C" int cs_debug_set_trace(long long* buf) {
   return CS_OK;
 }
 
+// LDS footprint of the 16-row kernel: bias table + three ring slots (cs_mlp_split16_launch_w)
+static bool cs_split16_fits(const CsMlpDev& n, int waves) {
+  const size_t nthr = 64 * (size_t)waves, mx = (size_t)(n.nt > n.nto ? n.nt : n.nto);
+  const size_t slot_f4 = (mx * 3 * 64 + nthr - 1) / nthr * nthr;
+  const size_t bias = (((size_t)(2 * n.nb + 2) * n.bias_stride * 4) + 1023) & ~(size_t)1023;
+  return bias + 3 * slot_f4 * 16 <= 160 * 1024;
+}
+
 int cs_mlp_launch(const CsMlpArgs& a_in, hipStream_t stream) {
   CsMlpArgs a = a_in;
   a.dbg = g_trace;
   if (a.rows <= 0) return CS_OK;
   if (a.net.prog) return cs_prog_launch(a, stream);
   cs_split_cfg();
-  // 32-row tiles fill 256 CUs x 4 waves from 32 768 rows on; below a quarter of that the 16-row kernel's shorter
-  // chain wins
-  const bool tile16 = cs_mlp_arith() == CS_ARITH_BF16X3 && (g_split_tile == 16 || (g_split_tile == 0 && a.rows <= 8192));
+  const int waves16 = g_split16_waves ? g_split16_waves : (a.rows <= 20480 ? 4 : 8);
+  const bool tile16 = cs_mlp_arith() == CS_ARITH_BF16X3 && g_split_tile != 32 && cs_split16_fits(a.net, waves16);
   if (a.mode == CS_MLP_DEC && a.in == nullptr &&
       (a.latent_dist == CS_DIST_BETA || (cs_mlp_arith() == CS_ARITH_BF16X3 && !tile16))) {
     // Beta proposals are drawn by a kernel of their own; the fused kernel then reads Z as its input.
@@ -93,12 +103,10 @@ int cs_mlp_launch(const CsMlpArgs& a_in, hipStream_t stream) {
   if (a.mode == CS_MLP_DEC && a.gen_dist != CS_DIST_BERN)
     CS_REQUIRE(a.net.split == 2, "generator output must be (loc | scale)");
   if (tile16) {
-    // 8-wave workgroups (two waves per SIMD) once there are enough row tiles for every CU, else 4-wave ones
-    const int waves = g_split16_waves ? g_split16_waves : ((a.rows + 127) / 128 >= 256 ? 8 : 4);
     switch (a.net.nt) {
-      case 4: return cs_mlp_split16_launch_h64(a, stream, waves);
-      case 8: return cs_mlp_split16_launch_h128(a, stream, waves);
-      case 16: return cs_mlp_split16_launch_h256(a, stream, waves);
+      case 4: return cs_mlp_split16_launch_h64(a, stream, waves16);
+      case 8: return cs_mlp_split16_launch_h128(a, stream, waves16);
+      case 16: return cs_mlp_split16_launch_h256(a, stream, waves16);
     }
   }
   if (cs_mlp_arith() == CS_ARITH_BF16X3) {

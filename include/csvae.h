@@ -117,6 +117,11 @@ typedef struct {
 } cs_layer_desc;
 int cs_net_create(const cs_layer_desc* layers, int32_t n_layers, const float* blob, int64_t blob_floats,
                   int32_t in_dim, int32_t out_dim, int32_t out_split, cs_mlp_t** out);
+/* Activation workspace of a layer-program network for launches of up to `rows` network rows (rows are processed in
+ * passes bounded by a 6 GiB workspace).  Without it the first launch that needs a larger workspace allocates it
+ * (and frees the smaller one after waiting for the device) inside the call; after cs_net_reserve(net, rows) no
+ * launch of <= rows rows allocates.  A no-op for fused-MLP handles, which have no workspace. */
+int cs_net_reserve(cs_mlp_t* net, int64_t rows);
 
 /* counter-RNG key */
 typedef struct {
@@ -400,9 +405,14 @@ int cs_rng_uniform64(const cs_rng* rng, uint32_t stream_id, int64_t rows, int32_
  * The setting is process-wide and applies to launches made after the call; the environment variable
  * CSVAE_MLP_ARITH (bf16x3 | f32) gives the initial value.  It also selects the kernels of the matrix-core
  * convolution / linear layers of layer-program networks (cs_net_create). */
-enum { CS_ARITH_F32 = 0, CS_ARITH_BF16X3 = 1 };
+enum { CS_ARITH_DEFAULT = -1, CS_ARITH_F32 = 0, CS_ARITH_BF16X3 = 1 };
 int cs_set_mlp_arith(int arith);
 int cs_get_mlp_arith(void);
+/* The same choice per network handle (fused MLP or layer program): it overrides the process-wide setting for
+ * every launch that uses the handle; CS_ARITH_DEFAULT returns the handle to the process-wide setting.  A caller
+ * that sets the arithmetic on its handles needs no process-wide state. */
+int cs_mlp_set_arith(cs_mlp_t* net, int arith);
+int cs_mlp_get_arith(const cs_mlp_t* net);
 
 /* Profiling hook (no counterpart in the reference): when buf != NULL every fused-MLP launch
  * writes 16 int64 per 16-row tile into buf (device memory, 16*ceil(rows/16) int64): clock stamps in

@@ -56,3 +56,50 @@ def test_arithmetic_setting_is_validated():
     assert _lib.lib().cs_set_mlp_arith(7) != 0
     assert b"unknown arithmetic" in _lib.lib().cs_last_error()
     assert _lib.get_mlp_arith() == prev
+
+
+def test_arithmetic_is_selectable_per_network_handle():
+    """cs_mlp_set_arith: a handle's own arithmetic overrides the process-wide setting (two networks with different
+    arithmetics in one process), CS_ARITH_DEFAULT hands it back."""
+    from oracle import cs_oracle as O
+    from vae_conditional_sampling_amd import _lib
+    from vae_conditional_sampling_amd.models import ResidualFCNetwork
+    w = O.make_resfc_weights(43, 64, 2, 256, seed=9)
+    x = torch.randn(500, 43, generator=torch.Generator().manual_seed(1)).cuda()
+    prev = _lib.get_mlp_arith()
+    try:
+        ref = {}
+        for arith in ("f32", "bf16x3"):
+            _lib.set_mlp_arith(arith)
+            ref[arith] = ResidualFCNetwork(43, 64, 2, 256).load_weight_dict(w).cuda().eval()(x).clone()
+        assert not torch.equal(ref["f32"], ref["bf16x3"])
+        _lib.set_mlp_arith("bf16x3")
+        a = ResidualFCNetwork(43, 64, 2, 256).load_weight_dict(w).cuda().eval()
+        b = ResidualFCNetwork(43, 64, 2, 256).load_weight_dict(w).cuda().eval()
+        a.packed().set_arith("f32")
+        assert a.packed().get_arith() == "f32" and b.packed().get_arith() == "bf16x3"
+        assert torch.equal(a(x), ref["f32"]) and torch.equal(b(x), ref["bf16x3"])
+        _lib.set_mlp_arith("f32")          # the process-wide setting moves; the pinned handle does not follow
+        b.packed().set_arith("bf16x3")
+        assert torch.equal(b(x), ref["bf16x3"]) and torch.equal(a(x), ref["f32"])
+        b.packed().set_arith(None)
+        assert torch.equal(b(x), ref["f32"])
+    finally:
+        _lib.set_mlp_arith(prev)
+
+
+def test_reserved_layer_program_workspace_gives_the_same_results():
+    """cs_net_reserve allocates a layer program's activation workspace ahead of the first launch (and is a no-op
+    for fused-MLP handles); results do not depend on who allocated it."""
+    from oracle import cs_oracle as O
+    from vae_conditional_sampling_amd.models import ResidualFCNetwork
+    w = O.make_resfc_weights(5, 6, 1, 512, seed=3)          # hidden 512: runs as a layer program
+    x = torch.randn(300, 5, generator=torch.Generator().manual_seed(2)).cuda()
+    lazy = ResidualFCNetwork(5, 6, 1, 512).load_weight_dict(w).cuda().eval()
+    y0 = lazy(x).clone()
+    eager = ResidualFCNetwork(5, 6, 1, 512).load_weight_dict(w).cuda().eval()
+    eager.packed().reserve(300)
+    eager.packed().reserve(10)     # never shrinks
+    assert torch.equal(eager(x), y0)
+    fused = ResidualFCNetwork(5, 6, 1, 64).load_weight_dict(O.make_resfc_weights(5, 6, 1, 64, seed=3)).cuda().eval()
+    fused.packed().reserve(1000)

@@ -257,3 +257,35 @@ def test_data_index_counts_positions_among_the_kept_rows(tmp_path):
     assert torch.equal(I, torch.arange(50))
     # rows were really dropped: the 50 kept rows are not the first 50 rows of the file
     assert not torch.equal(X[:, 0], torch.arange(0, 100, 2, dtype=torch.float32))
+
+
+REFERENCE_CONFIGS = "/root/reference/configs"
+
+
+@pytest.mark.skipif(not os.path.isdir(REFERENCE_CONFIGS), reason="the reference tree exists in the build container only")
+def test_every_reference_yaml_of_the_built_sampler_classes_constructs():
+    """Boundary check: each of the reference's sampling configurations whose test_class is one of the five sampler
+    classes built here constructs that class from its init_args unchanged (the YAML files are read as data)."""
+    import glob
+    import yaml
+    from vae_conditional_sampling_amd.sampling import test_step_vae_sampling as TS
+    built = {"TestVAELatentAdaptiveImportanceResampling", "TestVAEAdaptiveCollapsedMetropolisWithinGibbs",
+             "TestVAEMetropolisWithinGibbs", "TestVAEPseudoGibbs", "TestVAEImportanceResampling"}
+    n, seen = 0, set()
+    for path in sorted(glob.glob(os.path.join(REFERENCE_CONFIGS, "**", "*.yaml"), recursive=True)):
+        with open(path) as f:
+            try:
+                cfg = yaml.safe_load(f)
+            except yaml.YAMLError:
+                continue
+        tc = (cfg or {}).get("test_class") if isinstance(cfg, dict) else None
+        if not isinstance(tc, dict) or "class_path" not in tc:
+            continue
+        name = tc["class_path"].split(".")[-1]
+        if name not in built:
+            continue
+        obj = getattr(TS, name)(**(tc.get("init_args") or {}))
+        assert obj.max_iterations > 0, path
+        n += 1
+        seen.add(name)
+    assert n >= 200 and seen == built, (n, seen)

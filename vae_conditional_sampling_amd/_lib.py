@@ -149,6 +149,9 @@ def lib():
     L.cs_gen_loglik_rows.argtypes = [vp, i32, vp, vp, i64, i32, i32, vp, vp]
     L.cs_debug_set_workspace_budget.argtypes = [i64]
     L.cs_set_mlp_arith.argtypes = [i32]
+    L.cs_mlp_set_arith.argtypes = [vp, i32]
+    L.cs_mlp_get_arith.argtypes = [vp]
+    L.cs_net_reserve.argtypes = [vp, i64]
     L.cs_imputation_errors.argtypes = [vp, vp, vp, i64, i32, i32, vp, vp, vp]
     L.cs_latent_wasserstein.argtypes = [vp, vp, i64, i32, i32, vp, vp]
     L.cs_sample_impute.argtypes = [vp, i32, vp, C.POINTER(cs_rng), u32, vp, vp, i64, i32, i32, vp, vp, i32, vp]
@@ -211,6 +214,19 @@ def make_bufs(**tensors):
 class _PackedBase:
     handle = None
     out_dim = 0
+
+    def set_arith(self, name):
+        """Arithmetic of this network's matrix products ('f32', 'bf16x3', or None = the process-wide setting)."""
+        check(lib().cs_mlp_set_arith(self.handle, -1 if name is None else CS_ARITH[name]))
+
+    def get_arith(self):
+        v = lib().cs_mlp_get_arith(self.handle)
+        return next(k for k, c in CS_ARITH.items() if c == v)
+
+    def reserve(self, rows):
+        """Allocate the activation workspace of a layer-program network for launches of up to ``rows`` rows now,
+        so that no forward call allocates (cs_net_reserve; nothing to do for the fused MLP kernels)."""
+        check(lib().cs_net_reserve(self.handle, int(rows)))
 
     def forward(self, x):
         shape = x.shape

@@ -24,6 +24,7 @@ struct CsMlpDev {
   // 16-row-tile split-bf16 variant (cs_mlp_split16_kernel.inc): the same three bf16 terms in 16-row tile order;
   // bias table and output tile geometry are those of the exact-f32 kernel (bias, nto, tph)
   const f32x4* wstream16;
+  int arith;             // CS_ARITH_* of this network, or -1: the process default (cs_set_mlp_arith)
 };
 
 struct CsProgram;

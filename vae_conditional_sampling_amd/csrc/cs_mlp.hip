@@ -61,6 +61,16 @@ extern "C" int cs_set_mlp_arith(int arith) {
   return CS_OK;
 }
 extern "C" int cs_get_mlp_arith(void) { return cs_mlp_arith(); }
+extern "C" int cs_mlp_set_arith(cs_mlp_t* net, int arith) {
+  CS_REQUIRE(net, "null argument");
+  CS_REQUIRE(arith == CS_ARITH_DEFAULT || arith == CS_ARITH_F32 || arith == CS_ARITH_BF16X3, "unknown arithmetic");
+  net->dev.arith = arith;
+  if (net->prog) net->prog->arith = arith;
+  return CS_OK;
+}
+extern "C" int cs_mlp_get_arith(const cs_mlp_t* net) {
+  return net && net->dev.arith >= 0 ? net->dev.arith : cs_mlp_arith();
+}
 
 static long long* g_trace = nullptr;
 // Profiling hook: when set, every fused-MLP launch writes 16 int64 per wavefront (16-row tile)
@@ -86,10 +96,11 @@ int cs_mlp_launch(const CsMlpArgs& a_in, hipStream_t stream) {
   if (a.rows <= 0) return CS_OK;
   if (a.net.prog) return cs_prog_launch(a, stream);
   cs_split_cfg();
+  const int arith = a.net.arith >= 0 ? a.net.arith : cs_mlp_arith();
   const int waves16 = g_split16_waves ? g_split16_waves : (a.rows <= 20480 ? 4 : 8);
-  const bool tile16 = cs_mlp_arith() == CS_ARITH_BF16X3 && g_split_tile != 32 && cs_split16_fits(a.net, waves16);
+  const bool tile16 = arith == CS_ARITH_BF16X3 && g_split_tile != 32 && cs_split16_fits(a.net, waves16);
   if (a.mode == CS_MLP_DEC && a.in == nullptr &&
-      (a.latent_dist == CS_DIST_BETA || (cs_mlp_arith() == CS_ARITH_BF16X3 && !tile16))) {
+      (a.latent_dist == CS_DIST_BETA || (arith == CS_ARITH_BF16X3 && !tile16))) {
     // Beta proposals are drawn by a kernel of their own; the fused kernel then reads Z as its input.
     // The split-bf16 kernel runs one wavefront per SIMD, so nothing would cover the counter-RNG work of
     // its prologue: there too the proposals are drawn by the full-occupancy kernel first.
@@ -109,7 +120,7 @@ int cs_mlp_launch(const CsMlpArgs& a_in, hipStream_t stream) {
       case 16: return cs_mlp_split16_launch_h256(a, stream, waves16);
     }
   }
-  if (cs_mlp_arith() == CS_ARITH_BF16X3) {
+  if (arith == CS_ARITH_BF16X3) {
     switch (a.net.nt) {
       case 4: return cs_mlp_split_launch_h64(a, stream);
       case 8: return cs_mlp_split_launch_h128(a, stream);
@@ -336,6 +347,7 @@ extern "C" int cs_mlp_create(const cs_mlp_desc* d, const float* W0, const float*
   m->dev.nto3 = nto3;
   m->dev.bias_stride3 = bst3;
   m->dev.wstream16 = (const f32x4*)m->d_w16;
+  m->dev.arith = -1;
   *out = m;
   return CS_OK;
 }

@@ -23,6 +23,7 @@ struct CsProgram {
   float* ws = nullptr;
   int64_t ws_rows = 0;
   int device = 0;
+  int arith = -1;  // CS_ARITH_* of this network (cs_mlp_set_arith), or -1: the process default
 };
 
 // Runs the program in the role described by `a` (RAW / ENC / DEC, same meaning as for the

@@ -892,7 +892,7 @@ int launch_conv(const CsProgram& p, const CsLayer& L, const float* in, const flo
   a.w3 = nullptr;
   if (L.wp_off >= 0) {
     a.w = p.d_blob + L.wp_off;
-    if (L.wp3_off >= 0 && cs_mlp_arith() == CS_ARITH_BF16X3) {
+    if (L.wp3_off >= 0 && (p.arith >= 0 ? p.arith : cs_mlp_arith()) == CS_ARITH_BF16X3) {
       // split-bf16 arithmetic: the halo kernel for same-size 3x3 convolutions, else the generic one
       a.w3 = p.d_blob3 + L.wp3_off;
       const bool halo3 = d.op == CS_OP_CONV && d.ksize == 3 && d.stride == 1 && d.pad == 1 && d.upsample == 1 &&
@@ -1132,8 +1132,41 @@ extern "C" int cs_net_create(const cs_layer_desc* layers, int32_t n_layers, cons
   m->prog = p;
   m->dev.in_dim = in_dim; m->dev.out_dim = out_dim; m->dev.out_half = out_dim / out_split; m->dev.split = out_split;
   m->dev.prog = p;
+  m->dev.arith = -1;
   *out = m;
   return CS_OK;
+}
+
+// rows of the workspace that one pass of a launch of `rows` rows needs, and floats per row
+static int64_t prog_chunk_rows(const CsProgram* p, int64_t rows, int64_t* per_row_out) {
+  int64_t per_row = 0;
+  for (int b = 0; b < CS_NET_NBUF; ++b) per_row += (p->buf_elems[b] + 3) & ~(int64_t)3;  // every buffer 16-byte aligned
+  int64_t chunk = g_workspace_budget_bytes / (per_row * 4);
+  if (chunk < 1) chunk = 1;
+  if (chunk > rows) chunk = rows;
+  chunk = (chunk + 3) & ~(int64_t)3;
+  if (per_row_out) *per_row_out = per_row;
+  return chunk;
+}
+static int prog_grow_workspace(CsProgram* p, int64_t chunk, int64_t per_row) {
+  if (chunk <= p->ws_rows) return CS_OK;
+  if (p->ws) CS_HIP(hipFree(p->ws));  // waits for the work that still uses it
+  p->ws = nullptr;
+  p->ws_rows = 0;
+  CS_HIP(hipMalloc(&p->ws, (size_t)chunk * per_row * sizeof(float)));
+  p->ws_rows = chunk;
+  return CS_OK;
+}
+
+extern "C" int cs_net_reserve(cs_mlp_t* net, int64_t rows) {
+  CS_REQUIRE(net && rows >= 0, "bad argument");
+  if (!net->prog || rows == 0) return CS_OK;  // the fused kernels have no workspace
+  int dev = 0;
+  CS_HIP(hipGetDevice(&dev));
+  CS_REQUIRE(dev == net->prog->device, "network was created on another device");
+  int64_t per_row = 0;
+  const int64_t chunk = prog_chunk_rows(net->prog, rows, &per_row);
+  return prog_grow_workspace(net->prog, chunk, per_row);
 }
 
 int cs_prog_launch(const CsMlpArgs& a, hipStream_t stream) {
@@ -1146,23 +1179,18 @@ int cs_prog_launch(const CsMlpArgs& a, hipStream_t stream) {
   if (a.mode == CS_MLP_DEC && a.gen_dist == CS_DIST_BERN) CS_REQUIRE(a.net.out_dim == a.D, "generator output must be D logits");
   if (a.mode == CS_MLP_ENC) CS_REQUIRE(a.net.out_dim == 2 * a.Zd, "encoder output must be (loc | raw scale)");
 
-  // workspace: [staged input | scratch 1..4 | raw output] per row, for a chunk of rows
+  // workspace: [staged input | scratch 1..4 | raw output] per row, for a chunk of rows.  It only grows here when
+  // the caller has not reserved it (cs_net_reserve): growing allocates, and frees after waiting for the device.
   int64_t per_row = 0, prefix[CS_NET_NBUF];
-  for (int b = 0; b < CS_NET_NBUF; ++b) {
-    prefix[b] = per_row;
-    per_row += (p->buf_elems[b] + 3) & ~(int64_t)3;  // keep every buffer 16-byte aligned
+  {
+    int64_t off = 0;
+    for (int b = 0; b < CS_NET_NBUF; ++b) {
+      prefix[b] = off;
+      off += (p->buf_elems[b] + 3) & ~(int64_t)3;
+    }
   }
-  int64_t chunk = g_workspace_budget_bytes / (per_row * 4);
-  if (chunk < 1) chunk = 1;
-  if (chunk > a.rows) chunk = a.rows;
-  chunk = (chunk + 3) & ~(int64_t)3;
-  if (chunk > p->ws_rows) {
-    if (p->ws) CS_HIP(hipFree(p->ws));  // waits for the work that still uses it
-    p->ws = nullptr;
-    p->ws_rows = 0;
-    CS_HIP(hipMalloc(&p->ws, (size_t)chunk * per_row * sizeof(float)));
-    p->ws_rows = chunk;
-  }
+  const int64_t chunk = prog_chunk_rows(p, a.rows, &per_row);
+  if (int rc = prog_grow_workspace(p, chunk, per_row)) return rc;
   for (int64_t row0 = 0; row0 < a.rows; row0 += chunk) {
     const int64_t rows = a.rows - row0 < chunk ? a.rows - row0 : chunk;
     float* buf[CS_NET_NBUF];

@@ -54,6 +54,10 @@ def lair_workspace(model, B, K, R, I, device, slots=None):
         if len(cache) > 8:
             cache.clear()
         ws = cache[key] = LairWorkspace(model, B, K, R, I, device, slots)
+        # layer-program networks: allocate their activation workspace for this shape now, so that no iteration
+        # allocates inside a forward call (a no-op for the fused MLP kernels)
+        model.var_latent_network.packed().reserve(B * K)
+        model.generator_network.packed().reserve(I * B * (K + R))
     return ws
 
 

@@ -966,6 +966,8 @@ class TestVAEMetropolisWithinGibbs(_MetropolisWithinGibbsCommon):
 
         st, wk = self._chain_buffers(B, K, D, Zd, P, dev)
         L = _lib.lib()
+        model.var_latent_network.packed().reserve(B * K)   # layer programs: workspace allocated before the loop
+        model.generator_network.packed().reserve(B * K)
         h_enc = model.var_latent_network.packed().handle
         h_dec = model.generator_network.packed().handle
         stream = _lib.current_stream()
@@ -1070,6 +1072,8 @@ class TestVAEAdaptiveCollapsedMetropolisWithinGibbs(_MetropolisWithinGibbsCommon
                   use_prior=torch.empty(B, K, device=dev, dtype=torch.uint8),
                   z_alt=torch.empty(B, K, Zd, device=dev, dtype=torch.float32))
         L = _lib.lib()
+        model.var_latent_network.packed().reserve(B * K)   # layer programs: workspace allocated before the loop
+        model.generator_network.packed().reserve(B * K)
         h_enc = model.var_latent_network.packed().handle
         h_dec = model.generator_network.packed().handle
         stream = _lib.current_stream()

@@ -80,6 +80,50 @@ __device__ __forceinline__ void conv_store(const CsConvArgs& a, const f32x16 (&a
   }
 }
 
+// Coalesced form of conv_store for NHWC outputs whose channel count is a multiple of 32: the wavefront's PT x CT
+// accumulator tiles (32*PT pixels x 32*CT channels) are transposed through a wave-private LDS region `tw` of
+// 32*PT rows x (128*CT + 16) bytes, so that every store (and residual load) instruction of the wavefront covers
+// 1 KiB of whole pixel rows instead of 32 separate 32-byte pieces.  The caller has made sure that nobody reads the
+// region's previous contents any more.  row_gp = global pixel of the wavefront's first row.
+typedef __attribute__((address_space(3))) unsigned char conv_lds_byte;
+typedef __attribute__((address_space(3))) f32x4 conv_lds_f32x4;
+template <int CT, int PT>
+__device__ __forceinline__ void conv_store_rows(const CsConvArgs& a, const f32x16 (&acc)[PT][CT], conv_lds_byte* tw,
+                                                int64_t row_gp, int co0, int lane) {
+  constexpr int RL = CT * 128, RS = RL + 16, LPR = CT * 8, RPI = 64 / LPR;
+  const int h = lane >> 5, l31 = lane & 31;
+#pragma unroll
+  for (int p = 0; p < PT; ++p)
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        *(conv_lds_f32x4*)(tw + (p * 32 + l31) * RS + (ct * 32 + 8 * q + 4 * h) * 4) =
+            f32x4{acc[p][ct][4 * q], acc[p][ct][4 * q + 1], acc[p][ct][4 * q + 2], acc[p][ct][4 * q + 3]};
+  const int lr = lane / LPR, lc = (lane % LPR) * 4;
+  f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+  if (a.bias) bias4 = *(const f32x4*)(a.bias + co0 + lc);
+  f32x4 v[32 * PT / RPI];
+#pragma unroll
+  for (int i = 0; i < 32 * PT / RPI; ++i) {
+    const int row = i * RPI + lr;
+    const int64_t gp = row_gp + row;
+    v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (a.res && gp < a.npix) v[i] = *(const f32x4*)(a.res + gp * a.cout + co0 + lc);
+  }
+#pragma unroll
+  for (int i = 0; i < 32 * PT / RPI; ++i) {
+    const int row = i * RPI + lr;
+    const int64_t gp = row_gp + row;
+    f32x4 o = *(const conv_lds_f32x4*)(tw + row * RS + lc * 4) + bias4 + v[i];
+    if (a.relu) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[r] = fmaxf(o[r], 0.0f);
+    }
+    if (gp < a.npix) *(f32x4*)(a.out + gp * a.cout + co0 + lc) = o;
+  }
+}
+
 // Block = 4 wavefronts = 128 output pixels x (32*CT) output channels; a wavefront owns 32 pixels.
 // D[cout][pixel] = sum_k W[cout][k] * act[pixel][k]: the A operand is the weight tile, the B
 // operand the activation tile, so a lane ends up with 4 consecutive output channels of one pixel
@@ -311,60 +355,87 @@ __global__ void __launch_bounds__(256) cs_conv3x3_halo_kernel(const CsConvArgs a
 // Split-bf16 variant of cs_conv3x3_halo_kernel: every f32 operand is split exactly into three bf16
 // terms and a product is accumulated in f32 from the six leading term products on
 // v_mfma_f32_32x32x16_bf16 (float32-equivalent results at 6/16 of the matrix time; the arithmetic
-// of cs_mlp_split_kernel.inc).  The weights are split on the host; the halo tile is split as it is
-// staged (once per 32-channel chunk, reused by the 9 taps).  LDS rows are [term][32 k] bf16 = 192
-// bytes; a lane's 8 consecutive k of k-step s are the 16-byte slot 2s + (lane >> 5), stored at slot
-// ^ ((row >> 2) & 3) so that 16 consecutive rows fall into 16 different bank groups.
+// of cs_mlp_split_kernel.inc).
+//
+// A block of NW wavefronts covers 32*PT*NW consecutive output pixels x 32*CT output channels; a
+// wavefront owns PT pixel tiles x CT channel tiles (PT*CT accumulators of 16 registers).
+//   * Weights: split on the host into bricks [channel tile][k-step 2][term 3][lane 64] x 16 bytes, the
+//     order the lanes consume them, so a tile of a (tap, 32-channel chunk) step is W_B contiguous bytes and
+//     a fragment read is base + constant.  The tiles stream through a three-slot LDS ring by LDS-DMA
+//     (no registers, no LDS stores): while slot p is read, the copies into slot p+1 are issued in the first
+//     groups of the step; every wave waits for its own copies in front of the step's single barrier, which
+//     sits in the MIDDLE of the step (the previous contents of slot p+1 were last read in step p-2, which
+//     every wave had left before it passed the barrier of step p-1).  Step boundaries carry no barrier.
+//   * Activations: the window of 32*PT*NW + 2(W+1) input pixels that the 9 taps of the block's outputs read is
+//     split into its three terms as it is staged (once per 32-channel chunk) into rows of [term][32 k] bf16 =
+//     192 bytes; a lane's 8 consecutive k of k-step s are the 16-byte slot 2s + (lane >> 5), stored at slot
+//     ^ ((row >> 2) & 3): any 16 rows that are distinct modulo 16 fall into 16 different bank groups.  A tap
+//     whose input pixel lies outside the image reads a row of zeros instead (one select on the address).
+//   * Fragments are read one group (6*PT matrix instructions) ahead of their use, across step boundaries too;
+//     scheduling barriers pin that order.
 typedef unsigned u32x4n __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2n __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8n __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2n __attribute__((ext_vector_type(2)));
 typedef float f32x2n __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) unsigned char lds_byte;
+typedef __attribute__((address_space(3))) u32x4n lds_u32x4n;
 __device__ __forceinline__ unsigned conv_cvt_pk(float lo, float hi) {
   return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2n){lo, hi}, bf16x2n));
 }
-// NW = wavefronts per block: a block covers 32*NW consecutive output pixels.
-template <int CT, int NW>
+#define CS_CONV_MFMA32(A_, B_, C_) \
+  C_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8n, A_), __builtin_bit_cast(bf16x8n, B_), C_, 0, 0, 0)
+constexpr int CS_HALO_NPMAX = 10;  // staging passes: (32*PT*NW + 2*64) rows * 8 threads / (64*NW) threads
+template <int CT, int PT, int NW>
 __global__ void __launch_bounds__(64 * NW) cs_conv3x3_halo_split_kernel(const CsConvArgs a, int NR, int NP) {
-  constexpr int NTHR = 64 * NW, RPP = NTHR / 8;  // threads; halo rows staged per pass
-  constexpr int ROWB = 192, W_B = CT * 32 * ROWB;
-  constexpr int NPC = (W_B / 16 + NTHR - 1) / NTHR;  // 16-byte pieces of a weight tile per thread
-  extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
-  unsigned char* s_w = s_raw;               // [2][CT*32][ROWB]
-  unsigned char* s_halo = s_raw + 2 * W_B;  // [NR][ROWB]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr int NTHR = 64 * NW, RPP = NTHR / 8;  // threads; window rows staged per pass
+  constexpr int PX = 32 * PT;                    // pixels per wavefront
+  constexpr int ROWB = 192, W_B = CT * 6144;
+  constexpr int NPC = (W_B / 16 + NTHR - 1) / NTHR;  // 16-byte copies of a weight tile per thread
+  constexpr int G = 2 * CT, GB = G / 2;              // groups (k-step, channel tile) of a step; barrier group
+  extern __shared__ __attribute__((aligned(1024))) unsigned char s_raw[];
+  lds_byte* s_w = (lds_byte*)s_raw;      // [3][W_B]
+  lds_byte* s_halo = s_w + 3 * W_B;      // [NR][ROWB], then 256 bytes of zeros
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = (int)cs_scalar_u32((unsigned)tid >> 6);
   const int h = lane >> 5, l31 = lane & 31, c4 = tid & 7;
   const int W = a.win, H = a.hin;
   const int ncc = a.cin >> 5;
-  const int64_t p0 = (int64_t)blockIdx.x * (32 * NW);
+  const int64_t p0 = (int64_t)blockIdx.x * (PX * NW);
   const unsigned char* wblk = (const unsigned char*)a.w3 + (int64_t)blockIdx.y * W_B;
+  const unsigned zero_off = (unsigned)NR * ROWB;
+  if (NW == 8 && wave >= 4) __builtin_amdgcn_s_setprio(1);  // evens out issue arbitration between the two waves of a SIMD
 
-  const int64_t gp = p0 + wave * 32 + l31;
-  unsigned tapmask = 0;
-  {
+  unsigned tapmask[PT];
+  int row0[PT];
+#pragma unroll
+  for (int p = 0; p < PT; ++p) {
+    row0[p] = wave * PX + p * 32 + l31;
+    const int64_t gp = p0 + row0[p];
     const int hw = H * W;
     const int64_t g = gp < a.npix ? gp : 0;
     const int rem = (int)(g % hw);
     const int oh = rem / W, ow = rem - oh * W;
+    tapmask[p] = 0;
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
       const int ih = oh + t / 3 - 1, iw = ow + t % 3 - 1;
-      if (gp < a.npix && ih >= 0 && ih < H && iw >= 0 && iw < W) tapmask |= 1u << t;
+      if (gp < a.npix && ih >= 0 && ih < H && iw >= 0 && iw < W) tapmask[p] |= 1u << t;
     }
   }
 
-  f32x16 acc[CT];
+  f32x16 acc[PT][CT];
 #pragma unroll
-  for (int ct = 0; ct < CT; ++ct)
+  for (int p = 0; p < PT; ++p)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[ct][r] = 0.0f;
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[p][ct][r] = 0.0f;
 
-  constexpr int NPMAX = 8;  // (32*NW + 2*64) rows / RPP rows per pass <= 8
-  f32x4 rh[NPMAX];
-  u32x4n rw[NPC];
+  f32x4 rh[CS_HALO_NPMAX];
   auto fetch_halo = [&](int cc) {
 #pragma unroll
-    for (int p = 0; p < NPMAX; ++p) {
+    for (int p = 0; p < CS_HALO_NPMAX; ++p) {
       const int row = (tid >> 3) + RPP * p;
       const int64_t q = p0 - (W + 1) + row;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -374,7 +445,7 @@ __global__ void __launch_bounds__(64 * NW) cs_conv3x3_halo_split_kernel(const Cs
   };
   auto stash_halo = [&]() {
 #pragma unroll
-    for (int p = 0; p < NPMAX; ++p) {
+    for (int p = 0; p < CS_HALO_NPMAX; ++p) {
       const int row = (tid >> 3) + RPP * p;
       if (p < NP && row < NR) {
         // 4 consecutive k of one row -> 3 terms x 4 bf16
@@ -385,85 +456,147 @@ __global__ void __launch_bounds__(64 * NW) cs_conv3x3_halo_split_kernel(const Cs
         const unsigned a1 = conv_cvt_pk(r0, r1), b1 = conv_cvt_pk(r2, r3);
         const unsigned a2 = conv_cvt_pk(r0 - __uint_as_float(a1 << 16), r1 - __uint_as_float(a1 & 0xffff0000u));
         const unsigned b2 = conv_cvt_pk(r2 - __uint_as_float(b1 << 16), r3 - __uint_as_float(b1 & 0xffff0000u));
-        unsigned char* dst = s_halo + row * ROWB + (((c4 >> 1) ^ ((row >> 2) & 3)) << 4) + ((c4 & 1) << 3);
-        *(u32x2n*)(dst) = u32x2n{a0, b0};
-        *(u32x2n*)(dst + 64) = u32x2n{a1, b1};
-        *(u32x2n*)(dst + 128) = u32x2n{a2, b2};
+        lds_byte* dst = s_halo + row * ROWB + (((c4 >> 1) ^ ((row >> 2) & 3)) << 4) + ((c4 & 1) << 3);
+        *(__attribute__((address_space(3))) u32x2n*)(dst) = u32x2n{a0, b0};
+        *(__attribute__((address_space(3))) u32x2n*)(dst + 64) = u32x2n{a1, b1};
+        *(__attribute__((address_space(3))) u32x2n*)(dst + 128) = u32x2n{a2, b2};
       }
     }
   };
-  auto fetch_w = [&](int t) {
-    const unsigned char* wt = wblk + (int64_t)t * a.cout_p * ROWB;
-#pragma unroll
-    for (int i = 0; i < NPC; ++i) {
-      const int idx = tid + NTHR * i;
-      if (idx < W_B / 16) rw[i] = *(const u32x4n*)(wt + idx * 16);
+  // LDS-DMA of weight tile t into ring slot `slot`: thread copy r moves 16 bytes at r*NTHR*16 + tid*16
+  const unsigned dma_off = (unsigned)tid * 16u;
+  const unsigned ring_lds = cs_scalar_u32((unsigned)(size_t)s_w) + (unsigned)wave * 1024u;
+  auto dma_copy = [&](int t, int slot, int r) {
+    if (r * NTHR * 16 + wave * 1024 < W_B) {
+      const unsigned long long src = (unsigned long long)(wblk + (int64_t)t * a.cout_p * ROWB + (int64_t)r * NTHR * 16);
+      const void* ssrc =
+          (const void*)(((unsigned long long)cs_scalar_u32((unsigned)(src >> 32)) << 32) | cs_scalar_u32((unsigned)src));
+      cs_dma16(ssrc, dma_off, ring_lds + (unsigned)(slot * W_B + r * NTHR * 16));
     }
   };
-  auto stash_w = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < NPC; ++i) {
-      const int idx = tid + NTHR * i;
-      if (idx < W_B / 16) *(u32x4n*)(s_w + buf * W_B + idx * 16) = rw[i];
-    }
+  // activation fragment address of pixel tile p for tap `tap`, k-step 0 (k-step 1: ^ 32)
+  auto b_addr = [&](int tap, int p) -> unsigned {
+    const int rowB = row0[p] + (tap / 3) * W + (tap % 3);
+    const unsigned o = (unsigned)rowB * ROWB + (unsigned)((h ^ ((rowB >> 2) & 3)) << 4);
+    return ((tapmask[p] >> tap) & 1u) ? o : zero_off + (unsigned)(h << 4);
   };
 
   fetch_halo(0);
-  fetch_w(0);
-  const int swzA = (l31 >> 2) & 3;
-  int step = 0;
+#pragma unroll
+  for (int r = 0; r < NPC; ++r) dma_copy(0 * ncc + 0, 0, r);
+  if (tid < 16) *(lds_u32x4n*)(s_halo + zero_off + tid * 16) = u32x4n{0u, 0u, 0u, 0u};
+  stash_halo();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  u32x4n wr[2][3];
+  u32x4n br[2][PT][3];
+  unsigned bo[PT], bn[PT];
+  const lds_byte* wl = s_w + lane * 16;
   for (int cc = 0; cc < ncc; ++cc) {
-    __syncthreads();  // every read of the previous halo tile is done
-    stash_halo();
-    for (int tap = 0; tap < 9; ++tap, ++step) {
-      const int buf = step & 1;
-      stash_w(buf);  // this stage was last read two steps ago, behind the previous step's barrier
-      __syncthreads();
+    // first fragments of the chunk: group 0 of tap 0
+#pragma unroll
+    for (int tm = 0; tm < 3; ++tm) wr[0][tm] = *(const lds_u32x4n*)(wl + tm * 1024);
+#pragma unroll
+    for (int p = 0; p < PT; ++p) {
+      bo[p] = b_addr(0, p);
+#pragma unroll
+      for (int tm = 0; tm < 3; ++tm) br[0][p][tm] = *(const lds_u32x4n*)(s_halo + bo[p] + tm * 64);
+    }
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int slot = tap % 3, nslot = (tap + 1) % 3;
+      const bool more = tap < 8 || cc + 1 < ncc;                  // a step follows this one
+      const int tnext = tap < 8 ? (tap + 1) * ncc + cc : cc + 1;  // its weight tile
       if (tap < 8) {
-        fetch_w((tap + 1) * ncc + cc);
-      } else if (cc + 1 < ncc) {
-        fetch_w(cc + 1);
-        fetch_halo(cc + 1);
+#pragma unroll
+        for (int p = 0; p < PT; ++p) bn[p] = b_addr(tap + 1, p);
       }
-      const int rowB = wave * 32 + l31 + (tap / 3) * W + (tap % 3);
-      const unsigned char* bp = s_halo + rowB * ROWB;
-      const int swzB = (rowB >> 2) & 3;
-      const unsigned char* ap = s_w + buf * W_B + l31 * ROWB;
-      const bool inside = (tapmask >> tap) & 1u;
 #pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        const int slot = 2 * s + h;
-        u32x4n b[3];
-#pragma unroll
-        for (int tm = 0; tm < 3; ++tm) {
-          b[tm] = *(const u32x4n*)(bp + tm * 64 + ((slot ^ swzB) << 4));
-          if (!inside) b[tm] = u32x4n{0u, 0u, 0u, 0u};
+      for (int g = 0; g < G; ++g) {
+        const int s = g / CT, ct = g % CT;
+        if (g == GB) {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+          __builtin_amdgcn_sched_barrier(0);
+          // the next chunk's window: requested behind the barrier of tap 5, so that it has a whole step before
+          // the next wait for the DMA copies also waits for it
+          if (tap == 5 && cc + 1 < ncc) fetch_halo(cc + 1);
         }
+        // fragments of the next group (the first group of the next tap behind the last one)
+        if (g + 1 < G) {
+          const int s2 = (g + 1) / CT, ct2 = (g + 1) % CT;
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct) {
-          u32x4n w[3];
+          for (int tm = 0; tm < 3; ++tm)
+            wr[(g + 1) & 1][tm] = *(const lds_u32x4n*)(wl + slot * W_B + ((ct2 * 2 + s2) * 3 + tm) * 1024);
+        } else if (tap < 8) {
 #pragma unroll
-          for (int tm = 0; tm < 3; ++tm) w[tm] = *(const u32x4n*)(ap + ct * 32 * ROWB + tm * 64 + ((slot ^ swzA) << 4));
-#define CS_CONV_MFMA(A_, B_) \
-  acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8n, A_), __builtin_bit_cast(bf16x8n, B_), acc[ct], 0, 0, 0)
-          CS_CONV_MFMA(w[0], b[0]);
-          CS_CONV_MFMA(w[0], b[1]);
-          CS_CONV_MFMA(w[1], b[0]);
-          CS_CONV_MFMA(w[0], b[2]);
-          CS_CONV_MFMA(w[1], b[1]);
-          CS_CONV_MFMA(w[2], b[0]);
-#undef CS_CONV_MFMA
+          for (int tm = 0; tm < 3; ++tm) wr[0][tm] = *(const lds_u32x4n*)(wl + nslot * W_B + tm * 1024);
         }
+        if (ct == CT - 1) {
+          if (s == 0) {
+#pragma unroll
+            for (int p = 0; p < PT; ++p)
+#pragma unroll
+              for (int tm = 0; tm < 3; ++tm) br[1][p][tm] = *(const lds_u32x4n*)(s_halo + (bo[p] ^ 32u) + tm * 64);
+          } else if (tap < 8) {
+#pragma unroll
+            for (int p = 0; p < PT; ++p)
+#pragma unroll
+              for (int tm = 0; tm < 3; ++tm) br[0][p][tm] = *(const lds_u32x4n*)(s_halo + bn[p] + tm * 64);
+          }
+        }
+        const u32x4n(&w)[3] = wr[g & 1];
+#pragma unroll
+        for (int p = 0; p < PT; ++p) {
+          CS_CONV_MFMA32(w[0], br[s][p][0], acc[p][ct]);
+          CS_CONV_MFMA32(w[0], br[s][p][1], acc[p][ct]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (more && g < GB) {
+#pragma unroll
+          for (int r = 0; r < NPC; ++r)
+            if ((r < GB ? r : GB - 1) == g) dma_copy(tnext, nslot, r);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int p = 0; p < PT; ++p) {
+          CS_CONV_MFMA32(w[1], br[s][p][0], acc[p][ct]);
+          CS_CONV_MFMA32(w[0], br[s][p][2], acc[p][ct]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int p = 0; p < PT; ++p) {
+          CS_CONV_MFMA32(w[1], br[s][p][1], acc[p][ct]);
+          CS_CONV_MFMA32(w[2], br[s][p][0], acc[p][ct]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
+#pragma unroll
+      for (int p = 0; p < PT; ++p) bo[p] = bn[p];
+    }
+    if (cc + 1 < ncc) {
+      __syncthreads();  // every read of this chunk's window is done
+      stash_halo();
+      __syncthreads();
     }
   }
   cs_mfma_drain();
-  conv_store<CT>(a, acc, gp, blockIdx.y * (CT * 32), h);
+  if ((a.cout & 31) == 0 && !a.out_nchw) {
+    __syncthreads();  // the ring and the window are dead: the LDS becomes per-wave transposition space
+    conv_store_rows<CT, PT>(a, acc, (conv_lds_byte*)s_raw + wave * (PX * (CT * 128 + 16)), p0 + wave * PX,
+                            blockIdx.y * (CT * 32), lane);
+  } else {
+#pragma unroll
+    for (int p = 0; p < PT; ++p) conv_store<CT>(a, acc[p], p0 + row0[p], blockIdx.y * (CT * 32), h);
+  }
 }
+#undef CS_CONV_MFMA32
 
 // Split-bf16 variant of cs_conv_mfma_kernel (any kernel size / stride / upsampling, linear layers):
 // the activation tile of a chunk is split into its three bf16 terms as it is staged, the weight tile
-// comes pre-split (same row layout and slot swizzle as cs_conv3x3_halo_split_kernel).
+// comes pre-split in the brick order of cs_conv3x3_halo_split_kernel; the activation rows have its row layout and
+// slot swizzle.
 template <int CT>
 __global__ void __launch_bounds__(256) cs_conv_mfma_split_kernel(const CsConvArgs a) {
   constexpr int ROWB = 192, W_B = CT * 32 * ROWB;
@@ -558,7 +691,7 @@ __global__ void __launch_bounds__(256) cs_conv_mfma_split_kernel(const CsConvArg
   const int rowB = wave * 32 + l31;
   const unsigned char* bp = s_pix + rowB * ROWB;
   const int swz = (l31 >> 2) & 3;  // rowB and the weight rows differ from l31 by multiples of 32
-  const unsigned char* ap = s_w + l31 * ROWB;
+  const unsigned char* ap = s_w + lane * 16;  // weight bricks: [channel tile][k-step][term][lane] x 16 bytes
   for (int t = 0; t < nchunks; ++t) {
     __syncthreads();  // previous chunk's reads are done
     stash();
@@ -574,7 +707,7 @@ __global__ void __launch_bounds__(256) cs_conv_mfma_split_kernel(const CsConvArg
       for (int ct = 0; ct < CT; ++ct) {
         u32x4n w[3];
 #pragma unroll
-        for (int tm = 0; tm < 3; ++tm) w[tm] = *(const u32x4n*)(ap + ct * 32 * ROWB + tm * 64 + off);
+        for (int tm = 0; tm < 3; ++tm) w[tm] = *(const u32x4n*)(ap + ((ct * 2 + s) * 3 + tm) * 1024);
 #define CS_CONV_MFMA(A_, B_) \
   acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8n, A_), __builtin_bit_cast(bf16x8n, B_), acc[ct], 0, 0, 0)
         CS_CONV_MFMA(w[0], b[0]);
@@ -862,6 +995,13 @@ __global__ void __launch_bounds__(64) cs_dec_finish_kernel(const CsMlpArgs a, co
 }
 
 inline unsigned blocks_for(int64_t n) { return (unsigned)((n + 255) / 256); }
+// LDS bytes of cs_conv3x3_halo_split_kernel<CT, PT, NW>: three weight slots, the window, a row of zeros
+// (or, if larger, the epilogue's per-wave transposition regions)
+inline size_t halo3_lds(int ct, int pt, int nw, int win) {
+  const size_t loop = (size_t)3 * ct * 6144 + (size_t)(32 * pt * nw + 2 * (win + 1)) * 192 + 256;
+  const size_t store = (size_t)nw * 32 * pt * (ct * 128 + 16);
+  return loop > store ? loop : store;
+}
 
 // exact 3-way bf16 split of a finite float (round to nearest even at every step): v = t0 + t1 + t2
 inline void bf16_split3(float v, uint16_t t[3]) {
@@ -901,19 +1041,20 @@ int launch_conv(const CsProgram& p, const CsLayer& L, const float* in, const flo
       int dev = 0;
       CS_HIP(hipGetDevice(&dev));
       CS_REQUIRE(dev >= 0 && dev < 64, "device index out of range");
-#define CS_HALO3_LAUNCH(CT_, NW_)                                                                                        \
+#define CS_HALO3_LAUNCH(CT_, PT_, NW_)                                                                                   \
   do {                                                                                                                   \
-    const int NR = 32 * NW_ + 2 * (d.win + 1), NP = (NR * 8 + 64 * NW_ - 1) / (64 * NW_);                                \
-    const size_t lds = (size_t)(2 * CT_ * 32 + NR) * 192;                                                                \
+    const int NR = 32 * PT_ * NW_ + 2 * (d.win + 1), NP = (NR * 8 + 64 * NW_ - 1) / (64 * NW_);                          \
+    const size_t lds = halo3_lds(CT_, PT_, NW_, d.win);                                                                  \
+    CS_REQUIRE(NP <= CS_HALO_NPMAX && lds <= 160 * 1024, "halo window does not fit");                                     \
     static bool attr_set[64] = {};                                                                                       \
     if (!attr_set[dev]) {                                                                                                \
-      CS_HIP(hipFuncSetAttribute((const void*)cs_conv3x3_halo_split_kernel<CT_, NW_>,                                    \
+      CS_HIP(hipFuncSetAttribute((const void*)cs_conv3x3_halo_split_kernel<CT_, PT_, NW_>,                               \
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                               \
       attr_set[dev] = true;                                                                                              \
     }                                                                                                                    \
-    hipLaunchKernelGGL((cs_conv3x3_halo_split_kernel<CT_, NW_>),                                                         \
-                       dim3((unsigned)((a.npix + 32 * NW_ - 1) / (32 * NW_)), a.cout_p / (32 * CT_)), dim3(64 * NW_),   \
-                       lds, stream, a, NR, NP);                                                                          \
+    hipLaunchKernelGGL((cs_conv3x3_halo_split_kernel<CT_, PT_, NW_>),                                                    \
+                       dim3((unsigned)((a.npix + 32 * PT_ * NW_ - 1) / (32 * PT_ * NW_)), a.cout_p / (32 * CT_)),        \
+                       dim3(64 * NW_), lds, stream, a, NR, NP);                                                          \
   } while (0)
 #define CS_CONV3_LAUNCH(KERNEL_, LDS_, ...)                                                                             \
   do {                                                                                                                  \
@@ -925,11 +1066,12 @@ int launch_conv(const CsProgram& p, const CsLayer& L, const float* in, const flo
     hipLaunchKernelGGL(KERNEL_, dim3(gx, a.cout_p / (32 * CT_)), dim3(256), LDS_, stream, a, ##__VA_ARGS__);            \
   } while (0)
       if (halo3) {
-        // 8-wave blocks (256 pixels; one block per CU, two waves per SIMD) measured 3-7 % faster than 4-wave
-        // blocks at two blocks per CU: the halo rows are a smaller share of the staged window
-        if (a.cout_p % 128 == 0) CS_HALO3_LAUNCH(4, 8);
-        else if (a.cout_p % 64 == 0) CS_HALO3_LAUNCH(2, 8);
-        else CS_HALO3_LAUNCH(1, 4);
+        // one 8-wave block per CU (two waves per SIMD); 64-channel layers give a wavefront two pixel tiles so
+        // that a weight fragment feeds 12 matrix instructions
+        if (a.cout_p % 128 == 0) CS_HALO3_LAUNCH(4, 1, 8);
+        else if (a.cout_p % 64 == 0 && halo3_lds(2, 2, 8, d.win) <= 160 * 1024) CS_HALO3_LAUNCH(2, 2, 8);
+        else if (a.cout_p % 64 == 0) CS_HALO3_LAUNCH(2, 1, 8);
+        else CS_HALO3_LAUNCH(1, 2, 4);
       } else if (a.cout_p % 128 == 0) {
         constexpr int CT_ = 4;
         CS_CONV3_LAUNCH((cs_conv_mfma_split_kernel<CT_>), (size_t)(128 + CT_ * 32) * 192);
@@ -1088,22 +1230,26 @@ extern "C" int cs_net_create(const cs_layer_desc* layers, int32_t n_layers, cons
               packed.push_back(co < d.cout && ci < d.cin ? W[((int64_t)co * d.cin + ci) * kk + tap] : 0.0f);
             }
       {
-        // split-bf16 image of the same tiles: [tap][cin_p/32][cout_p] rows of [term 3][32 k] bf16, the 16-byte
-        // slots (8 k) of a row stored at slot ^ ((cout >> 2) & 3) as the kernels read them from LDS
+        // split-bf16 image of the same tiles: [tap][cin_p/32][cout_p/32] bricks of [k-step 2][term 3][lane 64] x 8
+        // bf16, the order in which the lanes of a wavefront consume them as the A operand of v_mfma_f32_32x32x16_bf16
+        // (lane l: channel l & 31 of the tile, k = 16*step + 8*(l >> 5) .. + 7)
         L.wp3_off = (int64_t)packed3.size();
         for (int tap = 0; tap < kk; ++tap)
           for (int cc = 0; cc < ncc; ++cc)
-            for (int co = 0; co < cout_p; ++co) {
-              uint16_t row[96] = {0};
-              for (int c = 0; c < 32; ++c) {
-                const int ci = cc * 32 + c;
-                const float v = co < d.cout && ci < d.cin ? W[((int64_t)co * d.cin + ci) * kk + tap] : 0.0f;
-                uint16_t t3[3];
-                bf16_split3(v, t3);
-                const int pos = (((c >> 3) ^ ((co >> 2) & 3)) << 3) + (c & 7);
-                for (int tm = 0; tm < 3; ++tm) row[tm * 32 + pos] = t3[tm];
+            for (int tile = 0; tile < cout_p / 32; ++tile) {
+              std::vector<uint16_t> brick(2 * 3 * 64 * 8, 0);
+              for (int l = 0; l < 64; ++l) {
+                const int co = tile * 32 + (l & 31);
+                for (int st = 0; st < 2; ++st)
+                  for (int j = 0; j < 8; ++j) {
+                    const int ci = cc * 32 + st * 16 + (l >> 5) * 8 + j;
+                    const float v = co < d.cout && ci < d.cin ? W[((int64_t)co * d.cin + ci) * kk + tap] : 0.0f;
+                    uint16_t t3[3];
+                    bf16_split3(v, t3);
+                    for (int tm = 0; tm < 3; ++tm) brick[((st * 3 + tm) * 64 + l) * 8 + j] = t3[tm];
+                  }
               }
-              packed3.insert(packed3.end(), row, row + 96);
+              packed3.insert(packed3.end(), brick.begin(), brick.end());
             }
       }
     }

@@ -42,10 +42,14 @@ def main():
     z = torch.randn(rows, dec.input_dim, device="cuda")
     for label, net, inp in (("enc", enc, x), ("dec", dec, z)):
         fl = program_flops(net)
-        for _ in range(2):
+        # the shader clock needs a few hundred milliseconds of load to settle: warm up for 0.5 s
+        t0 = time.perf_counter()
+        n1 = 0
+        while time.perf_counter() - t0 < 0.5:
             net(inp)
-        torch.cuda.synchronize()
-        n = 5
+            torch.cuda.synchronize()
+            n1 += 1
+        n = max(5, n1)
         t0 = time.perf_counter()
         for _ in range(n):
             net(inp)

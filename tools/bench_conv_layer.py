@@ -1,6 +1,6 @@
 """Time of single same-size 3x3 convolution layers (the halo kernels) through a layer program of N equal layers.
 
-    python tools/bench_conv_layer.py [rows] [layers] [channels,channels,...]
+    python tools/bench_conv_layer.py [rows] [layers] [channels[:resolution],...]
 
 Shapes: the residual stages of the reference's ResNet encoders / decoders (channels x resolution).  Prints the time per
 layer and the algorithmic TFLOP/s (2 * 9 * cin * cout * H * W per image) against the arithmetic's ceiling.
@@ -22,9 +22,9 @@ def main():
     arith = _lib.get_mlp_arith()
     peak = 157.3 if arith == "f32" else 2500.0 / 6
     g = torch.Generator().manual_seed(0)
-    only = [int(v) for v in sys.argv[3].split(",")] if len(sys.argv) > 3 else None
+    only = sys.argv[3].split(",") if len(sys.argv) > 3 else None
     for c, hw in SHAPES:
-        if only is not None and c not in only:
+        if only is not None and str(c) not in only and f"{c}:{hw}" not in only:
             continue
         b = _lib.ProgramBuilder(c * hw * hw, c * hw * hw, 1)
         w = torch.randn(c, c, 3, 3, generator=g) / (3 * c ** 0.5)
@@ -37,10 +37,14 @@ def main():
         net = b.build()
         x = torch.randn(rows, c * hw * hw, generator=g).cuda()
         net.reserve(rows)
-        for _ in range(2):
+        # the shader clock needs a few hundred milliseconds of load to settle: warm up for 0.4 s, time 0.4 s
+        t0 = time.perf_counter()
+        n1 = 0
+        while time.perf_counter() - t0 < 0.4:
             net.forward(x)
-        torch.cuda.synchronize()
-        n = 5
+            torch.cuda.synchronize()
+            n1 += 1
+        n = max(5, n1)
         t0 = time.perf_counter()
         for _ in range(n):
             net.forward(x)

@@ -7,10 +7,21 @@
 
 #include "cs_mlp.h"
 
+// How a nearest-neighbour-upsampled (x2) convolution runs on the matrix kernels.  Output pixel (2i + a, 2j + b) of
+// a 3x3 convolution over the upsampled image reads input rows {i - 1 + a, i + a} and columns {j - 1 + b, j + b} only,
+// two of its three kernel rows (columns) falling on the same input row (column): the layer is four 2x2 convolutions
+// of the input at its own resolution, one per output phase (a, b), with the coinciding taps' weights summed
+// (16 instead of 36 tap products per 2x2 outputs).  A 1x1 convolution is computed once per input pixel and
+// written to the four output pixels.
+enum CsUpsampleMode { CS_UP_NONE = 0, CS_UP_REPLICATE = 1, CS_UP_PHASES = 4 };
+
 struct CsLayer {
   cs_layer_desc d;
   int64_t wp_off;  // offset (floats) of the MFMA-packed weights in the device blob, -1: direct kernel
   int64_t wp3_off; // offset (bf16 entries) of the split-bf16 packed weights in d_blob3, -1: none
+  int up_mode = CS_UP_NONE;
+  int64_t wph_off[4] = {-1, -1, -1, -1};   // CS_UP_PHASES: packed weights of phase 2a + b (as wp_off / wp3_off)
+  int64_t wph3_off[4] = {-1, -1, -1, -1};
 };
 
 struct CsProgram {

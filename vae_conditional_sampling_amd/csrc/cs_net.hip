@@ -32,10 +32,23 @@ struct CsConvArgs {
   const float* bias;  // [cout] or null
   const float* res;   // [n, hout, wout, cout] or null
   float* out;
-  int cin, cout, hin, win, hout, wout, ksize, stride, pad, us, relu, in_nchw, out_nchw;
+  int cin, cout, hin, win, hout, wout, ksize, stride, pad_h, pad_w, us, relu, in_nchw, out_nchw;
   int cout_p;    // cout rounded up to 32 (mfma)
   int64_t npix;  // n * hout * wout
+  // Output placement.  osc = 1: pixel (i, j) of the hout x wout grid is output pixel (i, j).  osc = 2 (phase of a
+  // nearest-neighbour-upsampled convolution): it is pixel (2i + ooh, 2j + oow) of a 2*hout x 2*wout output; with
+  // rep it is written to all four pixels (2i + {0,1}, 2j + {0,1}), each with its own residual.
+  int osc, ooh, oow, rep;
 };
+
+__device__ __forceinline__ int64_t conv_out_pix(const CsConvArgs& a, int64_t gp, int ooh, int oow) {
+  if (a.osc == 1) return gp;
+  const int hw = a.hout * a.wout;
+  const int64_t n = gp / hw;
+  const int rem = (int)(gp - n * hw);
+  const int i = rem / a.wout, j = rem - i * a.wout;
+  return (n * (2 * a.hout) + 2 * i + ooh) * (2 * a.wout) + 2 * j + oow;
+}
 
 // Epilogue of the matrix-core convolutions: the lane holds pixel `gp`; register quad q of tile ct
 // holds channels co0 + 32ct + 8q + 4h + 0..3.  Bias, residual and ReLU are applied here.
@@ -43,23 +56,27 @@ template <int CT>
 __device__ __forceinline__ void conv_store(const CsConvArgs& a, const f32x16 (&acc)[CT], int64_t gp, int co0, int h) {
   if (gp >= a.npix) return;
   if ((a.cout & 31) == 0 && !a.out_nchw) {
-    float* orow = a.out + gp * a.cout + co0;
-    const float* rrow = a.res ? a.res + gp * a.cout + co0 : nullptr;
+    for (int ph = 0; ph < (a.rep ? 4 : 1); ++ph) {
+      const int64_t op = a.rep ? conv_out_pix(a, gp, ph >> 1, ph & 1) : conv_out_pix(a, gp, a.ooh, a.oow);
+      float* orow = a.out + op * a.cout + co0;
+      const float* rrow = a.res ? a.res + op * a.cout + co0 : nullptr;
 #pragma unroll
-    for (int ct = 0; ct < CT; ++ct)
+      for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int c = ct * 32 + 8 * q + 4 * h;
-        f32x4 v = {acc[ct][4 * q], acc[ct][4 * q + 1], acc[ct][4 * q + 2], acc[ct][4 * q + 3]};
-        if (a.bias) v += *(const f32x4*)(a.bias + co0 + c);
-        if (rrow) v += *(const f32x4*)(rrow + c);
-        if (a.relu) {
+        for (int q = 0; q < 4; ++q) {
+          const int c = ct * 32 + 8 * q + 4 * h;
+          f32x4 v = {acc[ct][4 * q], acc[ct][4 * q + 1], acc[ct][4 * q + 2], acc[ct][4 * q + 3]};
+          if (a.bias) v += *(const f32x4*)(a.bias + co0 + c);
+          if (rrow) v += *(const f32x4*)(rrow + c);
+          if (a.relu) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.0f);
+            for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.0f);
+          }
+          *(f32x4*)(orow + c) = v;
         }
-        *(f32x4*)(orow + c) = v;
-      }
+    }
   } else {
+    // scalar path: channel counts that are not multiples of 32, channel-major outputs (osc = 1 only)
     const int hw = a.hout * a.wout;
     const int64_t n = gp / hw;
     const int rem = (int)(gp - n * hw);
@@ -162,8 +179,8 @@ __global__ void __launch_bounds__(256) cs_conv_mfma_kernel(const CsConvArgs a) {
     const int64_t n = g / hw;
     const int rem = (int)(g - n * hw);
     const int oh = rem / a.wout, ow = rem - oh * a.wout;
-    ih0[p] = oh * a.stride - a.pad;
-    iw0[p] = ow * a.stride - a.pad;
+    ih0[p] = oh * a.stride - a.pad_h;
+    iw0[p] = ow * a.stride - a.pad_w;
     base[p] = n * a.hin * a.win;
   }
   const float* wblk = a.w + (int64_t)blockIdx.y * (CT * 32) * 32;
@@ -624,8 +641,8 @@ __global__ void __launch_bounds__(256) cs_conv_mfma_split_kernel(const CsConvArg
     const int64_t n = g / hw;
     const int rem = (int)(g - n * hw);
     const int oh = rem / a.wout, ow = rem - oh * a.wout;
-    ih0[p] = oh * a.stride - a.pad;
-    iw0[p] = ow * a.stride - a.pad;
+    ih0[p] = oh * a.stride - a.pad_h;
+    iw0[p] = ow * a.stride - a.pad_w;
     base[p] = n * a.hin * a.win;
   }
   const unsigned char* wblk = (const unsigned char*)a.w3 + (int64_t)blockIdx.y * W_B;
@@ -758,10 +775,10 @@ __global__ void __launch_bounds__(256) cs_conv_direct_kernel(const CsConvArgs a)
 #pragma unroll
   for (int v = 0; v < V; ++v) s[v] = 0.0f;
   for (int kh = 0; kh < a.ksize; ++kh) {
-    const int uh = oh * a.stride - a.pad + kh;
+    const int uh = oh * a.stride - a.pad_h + kh;
     if (uh < 0 || uh >= hup) continue;
     for (int kw = 0; kw < a.ksize; ++kw) {
-      const int uw = ow * a.stride - a.pad + kw;
+      const int uw = ow * a.stride - a.pad_w + kw;
       if (uw < 0 || uw >= wup) continue;
       const int sh = uh >> a.us, sw = uw >> a.us;
       const int tap = kh * a.ksize + kw;
@@ -1018,33 +1035,20 @@ inline void bf16_split3(float v, uint16_t t[3]) {
   }
 }
 
-int launch_conv(const CsProgram& p, const CsLayer& L, const float* in, const float* res, float* out, int64_t rows,
-                hipStream_t stream) {
-  const cs_layer_desc& d = L.d;
-  CsConvArgs a;
-  a.in = in; a.res = res; a.out = out;
-  a.bias = d.b_off >= 0 ? p.d_blob + d.b_off : nullptr;
-  a.cin = d.cin; a.cout = d.cout; a.hin = d.hin; a.win = d.win; a.hout = d.hout; a.wout = d.wout;
-  a.ksize = d.ksize; a.stride = d.stride; a.pad = d.pad; a.us = d.upsample == 2 ? 1 : 0; a.relu = d.relu;
-  a.in_nchw = d.in_nchw; a.out_nchw = d.out_nchw;
-  a.npix = rows * d.hout * d.wout;
-  a.cout_p = (d.cout + 31) & ~31;
-  a.w3 = nullptr;
-  if (L.wp_off >= 0) {
-    a.w = p.d_blob + L.wp_off;
-    if (L.wp3_off >= 0 && (p.arith >= 0 ? p.arith : cs_mlp_arith()) == CS_ARITH_BF16X3) {
-      // split-bf16 arithmetic: the halo kernel for same-size 3x3 convolutions, else the generic one
-      a.w3 = p.d_blob3 + L.wp3_off;
-      const bool halo3 = d.op == CS_OP_CONV && d.ksize == 3 && d.stride == 1 && d.pad == 1 && d.upsample == 1 &&
-                         d.hin == d.hout && d.win == d.wout && d.cin % 32 == 0 && d.win + 1 <= 64;
-      const unsigned gx = (unsigned)((a.npix + 127) / 128);
-      int dev = 0;
-      CS_HIP(hipGetDevice(&dev));
-      CS_REQUIRE(dev >= 0 && dev < 64, "device index out of range");
+// One matrix-kernel convolution described by `a` (a.w / a.w3 set; a.w3 non-null selects the split-bf16 kernels).
+int launch_conv_mfma(const CsConvArgs& a, hipStream_t stream) {
+  const bool same3 = a.ksize == 3 && a.stride == 1 && a.pad_h == 1 && a.pad_w == 1 && a.us == 0 && a.osc == 1 &&
+                     a.hin == a.hout && a.win == a.wout && a.cin % 32 == 0 && a.win + 1 <= 64;
+  if (a.w3) {
+    // split-bf16 arithmetic: the halo kernel for same-size 3x3 convolutions, else the generic one
+    const unsigned gx = (unsigned)((a.npix + 127) / 128);
+    int dev = 0;
+    CS_HIP(hipGetDevice(&dev));
+    CS_REQUIRE(dev >= 0 && dev < 64, "device index out of range");
 #define CS_HALO3_LAUNCH(CT_, PT_, NW_)                                                                                   \
   do {                                                                                                                   \
-    const int NR = 32 * PT_ * NW_ + 2 * (d.win + 1), NP = (NR * 8 + 64 * NW_ - 1) / (64 * NW_);                          \
-    const size_t lds = halo3_lds(CT_, PT_, NW_, d.win);                                                                  \
+    const int NR = 32 * PT_ * NW_ + 2 * (a.win + 1), NP = (NR * 8 + 64 * NW_ - 1) / (64 * NW_);                          \
+    const size_t lds = halo3_lds(CT_, PT_, NW_, a.win);                                                                  \
     CS_REQUIRE(NP <= CS_HALO_NPMAX && lds <= 160 * 1024, "halo window does not fit");                                     \
     static bool attr_set[64] = {};                                                                                       \
     if (!attr_set[dev]) {                                                                                                \
@@ -1065,35 +1069,33 @@ int launch_conv(const CsProgram& p, const CsLayer& L, const float* in, const flo
     }                                                                                                                   \
     hipLaunchKernelGGL(KERNEL_, dim3(gx, a.cout_p / (32 * CT_)), dim3(256), LDS_, stream, a, ##__VA_ARGS__);            \
   } while (0)
-      if (halo3) {
-        // one 8-wave block per CU (two waves per SIMD); 64-channel layers give a wavefront two pixel tiles so
-        // that a weight fragment feeds 12 matrix instructions
-        if (a.cout_p % 128 == 0) CS_HALO3_LAUNCH(4, 1, 8);
-        else if (a.cout_p % 64 == 0 && halo3_lds(2, 2, 8, d.win) <= 160 * 1024) CS_HALO3_LAUNCH(2, 2, 8);
-        else if (a.cout_p % 64 == 0) CS_HALO3_LAUNCH(2, 1, 8);
-        else CS_HALO3_LAUNCH(1, 2, 4);
-      } else if (a.cout_p % 128 == 0) {
-        constexpr int CT_ = 4;
-        CS_CONV3_LAUNCH((cs_conv_mfma_split_kernel<CT_>), (size_t)(128 + CT_ * 32) * 192);
-      } else if (a.cout_p % 64 == 0) {
-        constexpr int CT_ = 2;
-        CS_CONV3_LAUNCH((cs_conv_mfma_split_kernel<CT_>), (size_t)(128 + CT_ * 32) * 192);
-      } else {
-        constexpr int CT_ = 1;
-        CS_CONV3_LAUNCH((cs_conv_mfma_split_kernel<CT_>), (size_t)(128 + CT_ * 32) * 192);
-      }
+    if (same3) {
+      // one 8-wave block per CU (two waves per SIMD); 64-channel layers give a wavefront two pixel tiles so
+      // that a weight fragment feeds 12 matrix instructions
+      if (a.cout_p % 128 == 0) CS_HALO3_LAUNCH(4, 1, 8);
+      else if (a.cout_p % 64 == 0 && halo3_lds(2, 2, 8, a.win) <= 160 * 1024) CS_HALO3_LAUNCH(2, 2, 8);
+      else if (a.cout_p % 64 == 0) CS_HALO3_LAUNCH(2, 1, 8);
+      else CS_HALO3_LAUNCH(1, 2, 4);
+    } else if (a.cout_p % 128 == 0) {
+      constexpr int CT_ = 4;
+      CS_CONV3_LAUNCH((cs_conv_mfma_split_kernel<CT_>), (size_t)(128 + CT_ * 32) * 192);
+    } else if (a.cout_p % 64 == 0) {
+      constexpr int CT_ = 2;
+      CS_CONV3_LAUNCH((cs_conv_mfma_split_kernel<CT_>), (size_t)(128 + CT_ * 32) * 192);
+    } else {
+      constexpr int CT_ = 1;
+      CS_CONV3_LAUNCH((cs_conv_mfma_split_kernel<CT_>), (size_t)(128 + CT_ * 32) * 192);
+    }
 #undef CS_CONV3_LAUNCH
 #undef CS_HALO3_LAUNCH
-      CS_HIP(hipGetLastError());
-      return CS_OK;
-    }
-    const bool halo = d.ksize == 3 && d.stride == 1 && d.pad == 1 && d.upsample == 1 && d.hin == d.hout &&
-                      d.win == d.wout && d.cin % 32 == 0 && d.win + 1 <= 64;
-    const int NR = 128 + 2 * (d.win + 1), NP = (NR * 8 + 255) / 256;
+    CS_HIP(hipGetLastError());
+    return CS_OK;
+  }
+  const int NR = 128 + 2 * (a.win + 1), NP = (NR * 8 + 255) / 256;
 #define CS_CONV_LAUNCH(CT_)                                                                               \
   do {                                                                                                    \
     const unsigned gx = (unsigned)((a.npix + 127) / 128);                                                 \
-    if (halo && (size_t)(2 * CT_ * 32 + NR) * 36 * sizeof(float) <= 64 * 1024) {                          \
+    if (same3 && (size_t)(2 * CT_ * 32 + NR) * 36 * sizeof(float) <= 64 * 1024) {                         \
       const size_t lds = (size_t)(2 * CT_ * 32 + NR) * 36 * sizeof(float);                                \
       hipLaunchKernelGGL((cs_conv3x3_halo_kernel<CT_>), dim3(gx, a.cout_p / (32 * CT_)), dim3(256), lds,  \
                          stream, a, NR, NP);                                                              \
@@ -1103,20 +1105,64 @@ int launch_conv(const CsProgram& p, const CsLayer& L, const float* in, const flo
                          stream, a);                                                                      \
     }                                                                                                     \
   } while (0)
-    // Measured on the Omniglot / MNIST-GMM nets: 128-pixel x 128-channel blocks (two blocks per CU)
-    // beat 256-pixel blocks, 64-channel blocks and a two-stage LDS ring by 2-7 %.
-    if (a.cout_p % 128 == 0) CS_CONV_LAUNCH(4);
-    else if (a.cout_p % 64 == 0) CS_CONV_LAUNCH(2);
-    else CS_CONV_LAUNCH(1);
+  // Measured on the Omniglot / MNIST-GMM nets: 128-pixel x 128-channel blocks (two blocks per CU)
+  // beat 256-pixel blocks, 64-channel blocks and a two-stage LDS ring by 2-7 %.
+  if (a.cout_p % 128 == 0) CS_CONV_LAUNCH(4);
+  else if (a.cout_p % 64 == 0) CS_CONV_LAUNCH(2);
+  else CS_CONV_LAUNCH(1);
 #undef CS_CONV_LAUNCH
-  } else {
+  CS_HIP(hipGetLastError());
+  return CS_OK;
+}
+
+int launch_conv(const CsProgram& p, const CsLayer& L, const float* in, const float* res, float* out, int64_t rows,
+                hipStream_t stream) {
+  const cs_layer_desc& d = L.d;
+  CsConvArgs a;
+  a.in = in; a.res = res; a.out = out;
+  a.bias = d.b_off >= 0 ? p.d_blob + d.b_off : nullptr;
+  a.cin = d.cin; a.cout = d.cout; a.hin = d.hin; a.win = d.win; a.hout = d.hout; a.wout = d.wout;
+  a.ksize = d.ksize; a.stride = d.stride; a.pad_h = a.pad_w = d.pad; a.us = d.upsample == 2 ? 1 : 0; a.relu = d.relu;
+  a.in_nchw = d.in_nchw; a.out_nchw = d.out_nchw;
+  a.npix = rows * d.hout * d.wout;
+  a.cout_p = (d.cout + 31) & ~31;
+  a.osc = 1; a.ooh = a.oow = 0; a.rep = 0;
+  a.w3 = nullptr;
+  if (L.wp_off < 0) {
     a.w = p.d_blob + d.w_off;
     if (d.cout % 4 == 0 && !d.out_nchw)
       hipLaunchKernelGGL(cs_conv_direct_kernel<4>, dim3(blocks_for(a.npix * (d.cout / 4))), dim3(256), 0, stream, a);
     else
       hipLaunchKernelGGL(cs_conv_direct_kernel<1>, dim3(blocks_for(a.npix * d.cout)), dim3(256), 0, stream, a);
+    CS_HIP(hipGetLastError());
+    return CS_OK;
   }
-  CS_HIP(hipGetLastError());
+  const bool split = L.wp3_off >= 0 && (p.arith >= 0 ? p.arith : cs_mlp_arith()) == CS_ARITH_BF16X3;
+  if (L.up_mode == CS_UP_NONE) {
+    a.w = p.d_blob + L.wp_off;
+    if (split) a.w3 = p.d_blob3 + L.wp3_off;
+    return launch_conv_mfma(a, stream);
+  }
+  // upsampled convolutions run on the input's own grid (see CsUpsampleMode)
+  a.us = 0;
+  a.hout = d.hin; a.wout = d.win;
+  a.npix = rows * d.hin * d.win;
+  a.osc = 2;
+  if (L.up_mode == CS_UP_REPLICATE) {
+    a.rep = 1;
+    a.w = p.d_blob + L.wp_off;
+    if (split) a.w3 = p.d_blob3 + L.wp3_off;
+    return launch_conv_mfma(a, stream);
+  }
+  a.ksize = 2;
+  for (int ph = 0; ph < 4; ++ph) {
+    a.ooh = ph >> 1; a.oow = ph & 1;
+    a.pad_h = 1 - a.ooh; a.pad_w = 1 - a.oow;
+    a.w = p.d_blob + L.wph_off[ph];
+    a.w3 = split ? p.d_blob3 + L.wph3_off[ph] : nullptr;
+    const int rc = launch_conv_mfma(a, stream);
+    if (rc != CS_OK) return rc;
+  }
   return CS_OK;
 }
 
@@ -1218,22 +1264,21 @@ extern "C" int cs_net_create(const cs_layer_desc* layers, int32_t n_layers, cons
     L.wp_off = -1;
     L.wp3_off = -1;
     if (mfma_eligible(d)) {
-      // [tap][cin_p/32][cout_p][32], zero padded
-      L.wp_off = blob_floats + (int64_t)packed.size();
-      const int kk = d.ksize * d.ksize, ncc = (d.cin + 31) / 32, cout_p = (d.cout + 31) & ~31;
-      const float* W = blob + d.w_off;
-      for (int tap = 0; tap < kk; ++tap)
-        for (int cc = 0; cc < ncc; ++cc)
-          for (int co = 0; co < cout_p; ++co)
-            for (int c = 0; c < 32; ++c) {
-              const int ci = cc * 32 + c;
-              packed.push_back(co < d.cout && ci < d.cin ? W[((int64_t)co * d.cin + ci) * kk + tap] : 0.0f);
-            }
-      {
-        // split-bf16 image of the same tiles: [tap][cin_p/32][cout_p/32] bricks of [k-step 2][term 3][lane 64] x 8
-        // bf16, the order in which the lanes of a wavefront consume them as the A operand of v_mfma_f32_32x32x16_bf16
-        // (lane l: channel l & 31 of the tile, k = 16*step + 8*(l >> 5) .. + 7)
-        L.wp3_off = (int64_t)packed3.size();
+      // Packs weights Wsrc [cout][cin][kk] for the matrix kernels: f32 as [tap][cin_p/32][cout_p][32], zero padded, and
+      // the split-bf16 image [tap][cin_p/32][cout_p/32] bricks of [k-step 2][term 3][lane 64] x 8 bf16, the order in
+      // which the lanes of a wavefront consume them as the A operand of v_mfma_f32_32x32x16_bf16 (lane l: channel
+      // l & 31 of the tile, k = 16*step + 8*(l >> 5) .. + 7).
+      const int ncc = (d.cin + 31) / 32, cout_p = (d.cout + 31) & ~31;
+      auto pack = [&](const float* Wsrc, int kk, int64_t* off, int64_t* off3) {
+        *off = blob_floats + (int64_t)packed.size();
+        for (int tap = 0; tap < kk; ++tap)
+          for (int cc = 0; cc < ncc; ++cc)
+            for (int co = 0; co < cout_p; ++co)
+              for (int c = 0; c < 32; ++c) {
+                const int ci = cc * 32 + c;
+                packed.push_back(co < d.cout && ci < d.cin ? Wsrc[((int64_t)co * d.cin + ci) * kk + tap] : 0.0f);
+              }
+        *off3 = (int64_t)packed3.size();
         for (int tap = 0; tap < kk; ++tap)
           for (int cc = 0; cc < ncc; ++cc)
             for (int tile = 0; tile < cout_p / 32; ++tile) {
@@ -1243,7 +1288,7 @@ extern "C" int cs_net_create(const cs_layer_desc* layers, int32_t n_layers, cons
                 for (int st = 0; st < 2; ++st)
                   for (int j = 0; j < 8; ++j) {
                     const int ci = cc * 32 + st * 16 + (l >> 5) * 8 + j;
-                    const float v = co < d.cout && ci < d.cin ? W[((int64_t)co * d.cin + ci) * kk + tap] : 0.0f;
+                    const float v = co < d.cout && ci < d.cin ? Wsrc[((int64_t)co * d.cin + ci) * kk + tap] : 0.0f;
                     uint16_t t3[3];
                     bf16_split3(v, t3);
                     for (int tm = 0; tm < 3; ++tm) brick[((st * 3 + tm) * 64 + l) * 8 + j] = t3[tm];
@@ -1251,6 +1296,33 @@ extern "C" int cs_net_create(const cs_layer_desc* layers, int32_t n_layers, cons
               }
               packed3.insert(packed3.end(), brick.begin(), brick.end());
             }
+      };
+      const float* W = blob + d.w_off;
+      const bool up2 = d.op == CS_OP_CONV && d.upsample == 2 && d.stride == 1 && !d.out_nchw && d.cout % 32 == 0;
+      if (up2 && d.ksize == 3 && d.pad == 1) {
+        // phase (a, b): 2x2 taps (dh, dw) over input rows i - 1 + a + dh; kernel rows kh with (2i + a + kh - 1) >> 1
+        // equal to that row are summed (float64, rounded once), likewise the columns
+        L.up_mode = CS_UP_PHASES;
+        std::vector<float> Wph((size_t)d.cout * d.cin * 4);
+        for (int ph = 0; ph < 4; ++ph) {
+          const int pa = ph >> 1, pb = ph & 1;
+          for (int64_t cc = 0; cc < (int64_t)d.cout * d.cin; ++cc)
+            for (int dh = 0; dh < 2; ++dh)
+              for (int dw = 0; dw < 2; ++dw) {
+                double sum = 0.0;
+                for (int kh = 0; kh < 3; ++kh)
+                  for (int kw = 0; kw < 3; ++kw)
+                    if (((pa + kh + 1) >> 1) - 1 + (1 - pa) == dh && ((pb + kw + 1) >> 1) - 1 + (1 - pb) == dw)
+                      sum += (double)W[cc * 9 + kh * 3 + kw];
+                Wph[cc * 4 + dh * 2 + dw] = (float)sum;
+              }
+          pack(Wph.data(), 4, &L.wph_off[ph], &L.wph3_off[ph]);
+        }
+        L.wp_off = L.wph_off[0];
+        L.wp3_off = L.wph3_off[0];
+      } else {
+        if (up2 && d.ksize == 1 && d.pad == 0) L.up_mode = CS_UP_REPLICATE;
+        pack(W, d.ksize * d.ksize, &L.wp_off, &L.wp3_off);
       }
     }
     p->layers.push_back(L);

@@ -760,14 +760,25 @@ __global__ void __launch_bounds__(256) cs_conv_direct_kernel(const CsConvArgs a)
     }
     __syncthreads();
   }
-  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int cv = a.cout / V;
-  if (idx >= a.npix * cv) return;
-  const int co = (int)(idx % cv) * V;
-  const int64_t gp = idx / cv;
+  // grid-stride: the staged weights serve many outputs
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < a.npix * cv; idx += (int64_t)gridDim.x * 256) {
   const int hw = a.hout * a.wout;
-  const int64_t n = gp / hw;
-  const int rem = (int)(gp - n * hw);
+  int co;
+  int64_t gp, n;
+  int rem;
+  if (a.npix * cv < ((int64_t)1 << 31)) {  // 32-bit divisions: a 64-bit one costs about as much as the whole tap loop
+    const unsigned i32 = (unsigned)idx, g32 = i32 / (unsigned)cv, n32 = g32 / (unsigned)hw;
+    co = (int)(i32 - g32 * (unsigned)cv) * V;
+    gp = g32;
+    n = n32;
+    rem = (int)(g32 - n32 * (unsigned)hw);
+  } else {
+    co = (int)(idx % cv) * V;
+    gp = idx / cv;
+    n = gp / hw;
+    rem = (int)(gp - n * hw);
+  }
   const int oh = rem / a.wout, ow = rem - oh * a.wout;
   const int hup = a.hin << a.us, wup = a.win << a.us;
   const int64_t wstride = (int64_t)a.cin * kk;  // between output channels
@@ -812,7 +823,74 @@ __global__ void __launch_bounds__(256) cs_conv_direct_kernel(const CsConvArgs a)
   } else {
     a.out[gp * a.cout + co] = s[0];
   }
+  }
 }
+
+// Convolutions with at most 4 output channels over NHWC inputs of 32k channels (the decoders' last layer): bound by
+// reading the input once, and the matrix kernels would pad the outputs to 32.  Plain f32 FMAs (exact float32
+// arithmetic in either mode).  cin / 4 lanes share a pixel, each holds 4 consecutive input channels (a 16-byte
+// load; a wavefront's loads of a tap are contiguous), the partial sums are reduced across the pixel's lanes.
+// Weights staged in LDS as [tap][cin][COUT].
+template <int COUT, int KS>
+__global__ void __launch_bounds__(256) cs_conv_fewout_kernel(const CsConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float s_wf[];
+  constexpr int kk = KS * KS;
+  for (int i = threadIdx.x; i < a.cout * a.cin * kk; i += 256) {
+    const int co = i / (a.cin * kk), r = i - co * (a.cin * kk);  // r = ci*kk + tap
+    const int ci = r / kk, tap = r - ci * kk;
+    s_wf[(tap * a.cin + ci) * COUT + co] = a.w[i];
+  }
+  __syncthreads();
+  const int lpp = a.cin >> 2;                 // lanes per pixel: 8, 16, 32 or 64
+  const int ppb = 256 / lpp;                  // pixels per block and pass
+  const int sub = threadIdx.x & (lpp - 1);
+  const int hw = a.hout * a.wout;
+  const float* wp0 = s_wf + sub * 4 * COUT;
+  for (int64_t gp = (int64_t)blockIdx.x * ppb + threadIdx.x / lpp; gp < a.npix; gp += (int64_t)gridDim.x * ppb) {
+    const unsigned g32 = (unsigned)gp, n32 = g32 / (unsigned)hw;
+    const int rem = (int)(g32 - n32 * (unsigned)hw);
+    const int oh = rem / a.wout, ow = rem - oh * a.wout;
+    const int ih0 = oh * a.stride - a.pad_h, iw0 = ow * a.stride - a.pad_w;
+    // the lane's 4 channels of input pixel (ih0, iw0); taps are constant offsets from it
+    const float* ip0 = a.in + (((int64_t)n32 * a.hin + ih0) * a.win + iw0) * a.cin + sub * 4;
+    float s[COUT];
+#pragma unroll
+    for (int v = 0; v < COUT; ++v) s[v] = 0.0f;
+#pragma unroll
+    for (int kh = 0; kh < KS; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < KS; ++kw) {
+        const int ih = ih0 + kh, iw = iw0 + kw;
+        if (ih >= 0 && ih < a.hin && iw >= 0 && iw < a.win) {
+          const f32x4 x = *(const f32x4*)(ip0 + (kh * a.win + kw) * a.cin);
+          const float* wp = wp0 + (kh * KS + kw) * a.cin * COUT;
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int v = 0; v < COUT; ++v) s[v] = fmaf(x[c], wp[c * COUT + v], s[v]);
+        }
+      }
+    // the pixel's lanes are consecutive lanes of one wavefront (whole pixels per wavefront: no lane is idle here
+    // unless its whole pixel is past the end)
+#pragma unroll
+    for (int v = 0; v < COUT; ++v)
+      for (int o = lpp >> 1; o > 0; o >>= 1) s[v] += __shfl_xor(s[v], o);
+    if (sub == 0) {
+      const int64_t n = n32;
+#pragma unroll
+      for (int v = 0; v < COUT; ++v)
+        if (v < a.cout) {
+          float r = s[v];
+          if (a.bias) r += a.bias[v];
+          if (a.res) r += a.res[gp * a.cout + v];
+          if (a.relu) r = fmaxf(r, 0.0f);
+          if (a.out_nchw) a.out[(n * a.cout + v) * hw + rem] = r;
+          else a.out[gp * a.cout + v] = r;
+        }
+    }
+  }
+}
+
 
 // AdaptiveAvgPool2d((1,1)) over NHWC: one thread per (row, channel).
 // nn.LayerNorm(features) over the last dimension (eps 1e-5, biased variance) with its affine
@@ -1115,9 +1193,16 @@ int launch_conv_mfma(const CsConvArgs& a, hipStream_t stream) {
   return CS_OK;
 }
 
+// Convolutions to at most 4 channels from 32, 64, 128 or 256 NHWC channels: cs_conv_fewout_kernel.
+bool fewout_eligible(const cs_layer_desc& d) {
+  return d.op == CS_OP_CONV && d.cout <= 4 && (d.cin == 32 || d.cin == 64 || d.cin == 128 || d.cin == 256) && !d.in_nchw &&
+         d.upsample == 1 && (d.ksize == 3 || d.ksize == 1) && (int64_t)d.ksize * d.ksize * d.cin * 4 * 4 <= 48 * 1024;
+}
+
 int launch_conv(const CsProgram& p, const CsLayer& L, const float* in, const float* res, float* out, int64_t rows,
                 hipStream_t stream) {
   const cs_layer_desc& d = L.d;
+  CS_REQUIRE(rows * d.hout * d.wout < ((int64_t)1 << 31), "too many output pixels in one launch");
   CsConvArgs a;
   a.in = in; a.res = res; a.out = out;
   a.bias = d.b_off >= 0 ? p.d_blob + d.b_off : nullptr;
@@ -1128,12 +1213,29 @@ int launch_conv(const CsProgram& p, const CsLayer& L, const float* in, const flo
   a.cout_p = (d.cout + 31) & ~31;
   a.osc = 1; a.ooh = a.oow = 0; a.rep = 0;
   a.w3 = nullptr;
+  if (fewout_eligible(d)) {
+    a.w = p.d_blob + d.w_off;
+    const int ppb = 256 / (d.cin / 4);
+    const size_t lds = (size_t)d.ksize * d.ksize * d.cin * (d.cout <= 2 ? 2 : 4) * sizeof(float);
+    const int64_t nb = (a.npix + ppb - 1) / ppb;
+    const unsigned gx = (unsigned)(nb < 4096 ? nb : 4096);  // grid-stride: the weights are staged once per block
+    if (d.ksize == 3) {
+      if (d.cout <= 2) hipLaunchKernelGGL((cs_conv_fewout_kernel<2, 3>), dim3(gx), dim3(256), lds, stream, a);
+      else hipLaunchKernelGGL((cs_conv_fewout_kernel<4, 3>), dim3(gx), dim3(256), lds, stream, a);
+    } else {
+      if (d.cout <= 2) hipLaunchKernelGGL((cs_conv_fewout_kernel<2, 1>), dim3(gx), dim3(256), lds, stream, a);
+      else hipLaunchKernelGGL((cs_conv_fewout_kernel<4, 1>), dim3(gx), dim3(256), lds, stream, a);
+    }
+    CS_HIP(hipGetLastError());
+    return CS_OK;
+  }
   if (L.wp_off < 0) {
     a.w = p.d_blob + d.w_off;
+    const unsigned cap = 8192;
     if (d.cout % 4 == 0 && !d.out_nchw)
-      hipLaunchKernelGGL(cs_conv_direct_kernel<4>, dim3(blocks_for(a.npix * (d.cout / 4))), dim3(256), 0, stream, a);
+      hipLaunchKernelGGL(cs_conv_direct_kernel<4>, dim3(std::min(blocks_for(a.npix * (d.cout / 4)), cap)), dim3(256), 0, stream, a);
     else
-      hipLaunchKernelGGL(cs_conv_direct_kernel<1>, dim3(blocks_for(a.npix * d.cout)), dim3(256), 0, stream, a);
+      hipLaunchKernelGGL(cs_conv_direct_kernel<1>, dim3(std::min(blocks_for(a.npix * d.cout), cap)), dim3(256), 0, stream, a);
     CS_HIP(hipGetLastError());
     return CS_OK;
   }
@@ -1263,7 +1365,7 @@ extern "C" int cs_net_create(const cs_layer_desc* layers, int32_t n_layers, cons
     L.d = d;
     L.wp_off = -1;
     L.wp3_off = -1;
-    if (mfma_eligible(d)) {
+    if (mfma_eligible(d) && !fewout_eligible(d)) {
       // Packs weights Wsrc [cout][cin][kk] for the matrix kernels: f32 as [tap][cin_p/32][cout_p][32], zero padded, and
       // the split-bf16 image [tap][cin_p/32][cout_p/32] bricks of [k-step 2][term 3][lane 64] x 8 bf16, the order in
       // which the lanes of a wavefront consume them as the A operand of v_mfma_f32_32x32x16_bf16 (lane l: channel

@@ -654,25 +654,40 @@ __global__ void __launch_bounds__(256) cs_conv_mfma_split_kernel(const CsConvArg
     for (int r = 0; r < 16; ++r) acc[ct][r] = 0.0f;
   f32x4 rp[4];
   u32x4n rw[NPC];
+  // chunks run tap by tap, the 32-channel chunks of a tap consecutively: the four source rows of this thread are
+  // located once per tap (f_tap, f_cc: the next chunk to fetch), then advance by 32 channels
+  int f_tap = 0, f_cc = 0;
+  const float* srcp[4];
+  bool inb[4];
   auto fetch = [&](int t) {
-    const int tap = t / ncc, cc = t - tap * ncc;
-    const int kh = tap / a.ksize, kw = tap - kh * a.ksize;
+    if (f_cc == 0) {
+      const int kh = f_tap / a.ksize, kw = f_tap - kh * a.ksize;
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const int uh = ih0[p] + kh, uw = iw0[p] + kw;
+        inb[p] = pv[p] && uh >= 0 && uh < hup && uw >= 0 && uw < wup;
+        srcp[p] = a.in + ((base[p] + (int64_t)(uh >> a.us) * a.win + (uw >> a.us)) * a.cin + c4 * 4);
+      }
+    }
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
-      const int uh = ih0[p] + kh, uw = iw0[p] + kw;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (pv[p] && uh >= 0 && uh < hup && uw >= 0 && uw < wup) {
-        const int c0 = cc * 32 + c4 * 4;
-        const float* src = a.in + ((base[p] + (int64_t)(uh >> a.us) * a.win + (uw >> a.us)) * a.cin + c0);
+      if (inb[p]) {
+        const float* src = srcp[p] + f_cc * 32;
         if (cin_vec) {
           v = *(const f32x4*)src;
         } else {
+          const int c0 = f_cc * 32 + c4 * 4;
 #pragma unroll
           for (int r = 0; r < 4; ++r)
             if (c0 + r < a.cin) v[r] = src[r];
         }
       }
       rp[p] = v;
+    }
+    if (++f_cc == ncc) {
+      f_cc = 0;
+      ++f_tap;
     }
     const unsigned char* wt = wblk + (int64_t)t * a.cout_p * ROWB;
 #pragma unroll

@@ -209,7 +209,8 @@ class LairCabi:
         Kp = K + R
         res_bytes = (Kp * 2 * Zd * 4 + Kp * Zd * 4 + Kp * 4 + K * (2 * D * 4 + D * 4) + D) + (K * D * 4 + 2 * Kp * 4 + Kp * 8 + 12)
         split = arith == "bf16x3"
-        roofline = {"bound": "mfma", "kernel": ("cs_mlp_split_kernel" if split else "cs_mlp_kernel") + " (encoder launch)",
+        roofline = {"bound": "mfma", "kernel": ((("cs_mlp_split_kernel" if os.environ.get("CSVAE_SPLIT_TILE") == "32" else "cs_mlp_split16_kernel")
+                                                 if split else "cs_mlp_kernel") + " (encoder launch)"),
                     "achieved": enc_tf, "peak": peak, "unit": "TFLOP/s", "frac": enc_tf / peak,
                     "traffic": None, "flops_per_launch": enc_flops, "avg_launch_ms": enc_ms,
                     "note": ("algorithmic float32 FLOPs; each is executed as 6 bf16 matrix FLOPs, so peak = dense bf16 "

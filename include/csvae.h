@@ -264,6 +264,9 @@ typedef struct {
   double prior_mixture_probability;
   float proposal_temperature; /* var_proposal_temperature (0 = off), applied to the step's proposal */
   int32_t proposal_anneal;    /* CS_ANNEAL_* */
+  int32_t ring_u8;            /* 1: bufs.ring points to uint8_t [hist_len,B,K,D] holding x != 0 (the reference's
+                               * torch.bool queue for binary data, test_step_vae_sampling.py:1537-1541: a quarter of the
+                               * float ring's memory and traffic); the encoder must then be a layer program */
 } cs_acmwg_cfg;
 
 /* Variants of the Metropolis-within-Gibbs step that share the AC-MWG kernels.
@@ -325,6 +328,12 @@ int cs_acmwg_step(const cs_mlp_t* enc, const cs_mlp_t* dec, const cs_acmwg_cfg* 
 int cs_history_enqueue(float* ring, int64_t* avail, int32_t hist_len, int32_t new_tail, int32_t was_full,
                        const float* X, int64_t B, int32_t K, int32_t D, void* stream);
 /* update_available_timesteps (utils.py:94-99): avail[mask] = len (mask NULL: all chains). */
+/* The same two operations on a uint8 ring (binary data: the ring holds x != 0, reads give 0.0f / 1.0f). */
+int cs_history_enqueue_u8(uint8_t* ring, int64_t* avail, int32_t hist_len, int32_t new_tail, int32_t was_full,
+                          const float* X, int64_t B, int32_t K, int32_t D, void* stream);
+int cs_history_concat_u8(const float* X, const uint8_t* ring, int64_t B, int32_t K, int32_t D, int32_t H,
+                         const int32_t* slots, const int32_t* chain_of_proposal, const int64_t* chain_of_example,
+                         const cs_rng* rng, float* Xc, void* stream);
 int cs_history_set_available(int64_t* avail, const uint8_t* mask, int64_t chains, int64_t len, void* stream);
 
 /* out[row] = sum_d log N(Z[row,d]; 0, 1): reduce(prior_distr.log_prob(Z), '... d -> ...', 'sum')

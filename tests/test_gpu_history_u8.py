@@ -1,0 +1,73 @@
+"""uint8 history ring for binary data: the library's enqueue / concat on a uint8 ring give the values of the float ring
+(the reference's queue holds X.bool() for binary data, irwg/sampling/test_step_vae_sampling.py:1537-1541,
+irwg/sampling/utils.py:83-113).  The AC-MWG path over it is pinned by the Omniglot-like golden fixtures
+(tests/test_gpu_conv.py), whose sampler builds the uint8 ring for the convolutional encoder."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_uint8_queue_matches_float_queue():
+    from vae_conditional_sampling_amd.sampling.utils import (ImputationHistoryQueue,
+                                                              ImputationHistoryQueue_with_restrictedavailability)
+    g = torch.Generator().manual_seed(3)
+    B, K, D, T = 5, 3, 37, 4
+    qf = ImputationHistoryQueue(T, (B, K, D), dtype=torch.float32)
+    q8 = ImputationHistoryQueue(T, (B, K, D), dtype=torch.bool)
+    assert q8.history_queue.dtype == torch.uint8 and qf.history_queue.dtype == torch.float32
+    rf = ImputationHistoryQueue_with_restrictedavailability(T, (B, K, D), dtype=torch.float32)
+    r8 = ImputationHistoryQueue_with_restrictedavailability(T, (B, K, D), dtype=torch.bool)
+    rk = ImputationHistoryQueue_with_restrictedavailability(T, (B, K, D), dtype=torch.bool, compact=False)
+    assert r8.history_queue.dtype == torch.uint8 and rk.history_queue.dtype == torch.float32
+    for t in range(6):  # wraps the ring
+        X = (torch.rand(B, K, D, generator=g) < 0.4).float().cuda()
+        for q in (qf, q8, rf, r8):
+            q.enqueue_batch(X)
+        torch.cuda.synchronize()
+        assert torch.equal(q8.history_queue.float(), qf.history_queue)
+        assert torch.equal(r8.history_queue.float(), rf.history_queue)
+        assert torch.equal(r8.available_timesteps, rf.available_timesteps)
+        assert (q8.tail_idx, q8.full) == (qf.tail_idx, qf.full)
+    X = (torch.rand(B, K, D, generator=g) < 0.5).float().cuda()
+    slots = [1, 3]
+    cf = qf.concat_history(X, slots, chain_of_proposal=[0, 2])
+    c8 = q8.concat_history(X, slots, chain_of_proposal=[0, 2])
+    assert torch.equal(cf, c8)
+    coe = torch.randint(0, K, (B,), generator=g)
+    assert torch.equal(qf.concat_history(X, slots, chain_of_example=coe), q8.concat_history(X, slots, chain_of_example=coe))
+
+
+def test_acmwg_over_uint8_ring_equals_float_ring(monkeypatch):
+    """The convolutional Bernoulli model on binary data: identical chains whichever ring the sampler builds."""
+    from tests.helpers import conv_weights, make_conv_model
+    from tests.test_gpu_samplers import BASE_KW
+    from vae_conditional_sampling_amd.sampling import test_step_vae_sampling as T
+    from vae_conditional_sampling_amd.sampling import utils as U
+    enc_w, dec_w = conv_weights("omni_like", 7)
+    g = torch.Generator().manual_seed(5)
+    B, K, D = 3, 5, 784
+    X0 = (torch.rand(B, 1, D, generator=g) < 0.3).float().repeat(1, K, 1)
+    M = torch.rand(B, 1, D, generator=g) < 0.5
+    orig = U.ImputationHistoryQueue_with_restrictedavailability
+    runs = []
+    for compact in (True, False):
+        class Q(orig):
+            def __init__(self, *a, _c=compact, **kw):
+                kw["compact"] = _c
+                super().__init__(*a, **kw)
+        monkeypatch.setattr(T, "ImputationHistoryQueue_with_restrictedavailability", Q)
+        model = make_conv_model("omni_like", enc_w, dec_w, "normal", "bern")
+        s = T.TestVAEAdaptiveCollapsedMetropolisWithinGibbs(
+            num_pseudo_warmup_iterations=0, num_mwg_iterations=8, prior_mixture_probability=0.2, warmup_method="none",
+            num_copies=K, **BASE_KW)
+        s.set_model(model)
+        s.on_test_start()
+        s.rng_seed = 11
+        s.on_test_batch_start(None, 0)
+        Xi = s.basic_imputation(X0.cuda(), M.cuda())
+        out = [d["X"].clone() for d in s.sampler(Xi, M.cuda())]
+        assert (s.history.history_queue.dtype == torch.uint8) == compact
+        runs.append(torch.stack(out))
+    assert torch.equal(runs[0], runs[1])
+    assert not torch.equal(runs[0][0], runs[0][-1])

@@ -88,7 +88,7 @@ class cs_acmwg_cfg(C.Structure):
                 ("latent_dist", C.c_int32), ("gen_dist", C.c_int32), ("hist_len", C.c_int32),
                 ("hist_tail", C.c_int32), ("hist_full", C.c_int32), ("flags", C.c_int32),
                 ("prior_mixture_probability", C.c_double), ("proposal_temperature", C.c_float),
-                ("proposal_anneal", C.c_int32)]
+                ("proposal_anneal", C.c_int32), ("ring_u8", C.c_int32)]
 
 
 _ACMWG_BUF_FIELDS = ["X", "M", "Z_old", "gen_old", "z_old_prior_lp", "x_old_lp", "ring", "avail", "r_hist",
@@ -141,6 +141,8 @@ def lib():
     L.cs_history_concat.argtypes = [vp, vp, i64, i32, i32, i32, C.POINTER(i32), C.POINTER(i32), vp,
                                     C.POINTER(cs_rng), vp, vp]
     L.cs_history_enqueue.argtypes = [vp, vp, i32, i32, i32, vp, i64, i32, i32, vp]
+    L.cs_history_enqueue_u8.argtypes = L.cs_history_enqueue.argtypes
+    L.cs_history_concat_u8.argtypes = L.cs_history_concat.argtypes
     L.cs_history_set_available.argtypes = [vp, vp, i64, i64, vp]
     L.cs_final_resample.argtypes = [vp, vp, i64, i64, i32, i32, vp, C.POINTER(cs_rng), i64, vp, vp, vp, vp]
     L.cs_final_resample_static.argtypes = [vp, vp, i64, i64, i32, i32, vp, C.POINTER(cs_rng), i64, vp, vp, vp]

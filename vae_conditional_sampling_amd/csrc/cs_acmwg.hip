@@ -174,9 +174,12 @@ __global__ void __launch_bounds__(256) cs_acmwg_accept_kernel(const CsAcmwgArgs 
   }
   // x_m ~ p(x_m | z), imputation, ring write, new masked log-likelihood (:1744-1755)
   float* ring_row = nullptr;
+  uint8_t* ring_row8 = nullptr;  // binary ring: holds x != 0
   if (use_hist) {
     const int new_tail = (a.cfg.hist_tail + 1) % a.cfg.hist_len;
-    ring_row = a.b.ring + ((int64_t)new_tail * B * K + tc) * D;
+    const int64_t e = ((int64_t)new_tail * B * K + tc) * D;
+    if (a.cfg.ring_u8) ring_row8 = (uint8_t*)a.b.ring + e;
+    else ring_row = a.b.ring + e;
   }
   float* go = a.b.gen_old + tc * P;
   const float* gn = a.b.gen_new + tc * P;
@@ -251,6 +254,10 @@ __global__ void __launch_bounds__(256) cs_acmwg_accept_kernel(const CsAcmwgArgs 
         if (!bern) *(f32x4_u*)(go + D + d0) = b1;
         *(f32x4_u*)(Xr + d0) = xn4;
         if (ring_row) *(f32x4_u*)(ring_row + d0) = xn4;
+        if (ring_row8) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) ring_row8[d0 + r] = xn4[r] != 0.0f;
+        }
       } else {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
@@ -259,6 +266,7 @@ __global__ void __launch_bounds__(256) cs_acmwg_accept_kernel(const CsAcmwgArgs 
             if (!bern) go[D + d0 + r] = b1[r];
             Xr[d0 + r] = xn4[r];
             if (ring_row) ring_row[d0 + r] = xn4[r];
+            if (ring_row8) ring_row8[d0 + r] = xn4[r] != 0.0f;
           }
       }
     }
@@ -297,10 +305,11 @@ __global__ void __launch_bounds__(256) cs_gen_loglik_kernel(const float* gen, in
   if (lane == 0) out[t] = ll;
 }
 
-__global__ void cs_history_enqueue_kernel(float* ring_slot, const float* X, int64_t n, int64_t* avail, int64_t chains,
+template <typename T>
+__global__ void cs_history_enqueue_kernel(T* ring_slot, const float* X, int64_t n, int64_t* avail, int64_t chains,
                                           int was_full) {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t < n) ring_slot[t] = X[t];
+  if (t < n) ring_slot[t] = sizeof(T) == 1 ? (T)(X[t] != 0.0f) : (T)X[t];
   if (was_full && t < chains) {
     const int64_t av = avail[t];
     avail[t] = av > 0 ? av - 1 : 0;
@@ -389,6 +398,7 @@ extern "C" int cs_acmwg_step(const cs_mlp_t* enc, const cs_mlp_t* dec, const cs_
   e.net = enc->dev; e.mode = CS_MLP_ENC; e.rows = chains;
   if (use_hist) {
     e.in = b->ring; e.in_off = b->in_off;
+    e.in_u8 = c->ring_u8 ? 1 : 0;
   } else {
     e.in = b->X; e.in_stride = c->D;
   }
@@ -430,7 +440,7 @@ extern "C" int cs_acmwg_step(const cs_mlp_t* enc, const cs_mlp_t* dec, const cs_
 
 // LAIR's historical proposals: Xc[b] = (X[b, 0..K), ring[slots[h], b, chain] for h < H).
 struct CsHistConcatArgs {
-  const float* X; const float* ring; float* Xc; const int64_t* chain_of_example; CsPhilox rng;
+  const float* X; const float* ring; const uint8_t* ring8; float* Xc; const int64_t* chain_of_example; CsPhilox rng;
   int64_t B; int K, D, H; int use_chain_of_proposal;
   int slots[64]; int chain_of_proposal[64];
 };
@@ -458,19 +468,20 @@ __global__ void __launch_bounds__(256) cs_history_concat_kernel(const CsHistConc
       cs_philox_block(a.rng, CS_STREAM_HIST, a.rng.row_offset + b, 0, x);
       chain = (int)(((uint64_t)x[0] * (uint64_t)a.K) >> 32);
     }
-    v = a.ring[(((int64_t)a.slots[h] * a.B + b) * a.K + chain) * a.D + d];
+    const int64_t e = (((int64_t)a.slots[h] * a.B + b) * a.K + chain) * a.D + d;
+    v = a.ring8 ? (float)a.ring8[e] : a.ring[e];
   }
   a.Xc[t] = v;
 }
 
-extern "C" int cs_history_concat(const float* X, const float* ring, int64_t B, int32_t K, int32_t D, int32_t H,
-                                 const int32_t* slots, const int32_t* chain_of_proposal, const int64_t* chain_of_example,
-                                 const cs_rng* rng, float* Xc, void* stream) {
-  CS_REQUIRE(X && ring && Xc && slots && B >= 0 && K >= 1 && D >= 1, "bad argument");
+static int history_concat(const float* X, const float* ring, const uint8_t* ring8, int64_t B, int32_t K, int32_t D, int32_t H,
+                          const int32_t* slots, const int32_t* chain_of_proposal, const int64_t* chain_of_example,
+                          const cs_rng* rng, float* Xc, void* stream) {
+  CS_REQUIRE(X && (ring || ring8) && Xc && slots && B >= 0 && K >= 1 && D >= 1, "bad argument");
   CS_REQUIRE(H >= 1 && H <= 64, "number of historical proposals must be in [1,64]");
   if (B == 0) return CS_OK;
   CsHistConcatArgs a;
-  a.X = X; a.ring = ring; a.Xc = Xc; a.chain_of_example = chain_of_example; a.rng = cs_make_philox(rng);
+  a.X = X; a.ring = ring; a.ring8 = ring8; a.Xc = Xc; a.chain_of_example = chain_of_example; a.rng = cs_make_philox(rng);
   a.B = B; a.K = K; a.D = D; a.H = H; a.use_chain_of_proposal = chain_of_proposal != nullptr;
   for (int h = 0; h < 64; ++h) {
     a.slots[h] = h < H ? slots[h] : 0;
@@ -483,15 +494,38 @@ extern "C" int cs_history_concat(const float* X, const float* ring, int64_t B, i
   return CS_OK;
 }
 
-extern "C" int cs_history_enqueue(float* ring, int64_t* avail, int32_t hist_len, int32_t new_tail, int32_t was_full,
-                                  const float* X, int64_t B, int32_t K, int32_t D, void* stream) {
+extern "C" int cs_history_concat(const float* X, const float* ring, int64_t B, int32_t K, int32_t D, int32_t H,
+                                 const int32_t* slots, const int32_t* chain_of_proposal, const int64_t* chain_of_example,
+                                 const cs_rng* rng, float* Xc, void* stream) {
+  return history_concat(X, ring, nullptr, B, K, D, H, slots, chain_of_proposal, chain_of_example, rng, Xc, stream);
+}
+
+extern "C" int cs_history_concat_u8(const float* X, const uint8_t* ring, int64_t B, int32_t K, int32_t D, int32_t H,
+                                    const int32_t* slots, const int32_t* chain_of_proposal, const int64_t* chain_of_example,
+                                    const cs_rng* rng, float* Xc, void* stream) {
+  return history_concat(X, nullptr, ring, B, K, D, H, slots, chain_of_proposal, chain_of_example, rng, Xc, stream);
+}
+
+template <typename T>
+static int history_enqueue(T* ring, int64_t* avail, int32_t hist_len, int32_t new_tail, int32_t was_full, const float* X,
+                           int64_t B, int32_t K, int32_t D, void* stream) {
   CS_REQUIRE(ring && (avail || !was_full) && X && hist_len >= 1 && new_tail >= 0 && new_tail < hist_len, "bad argument");
   const int64_t chains = B * K, n = chains * D;
   if (n == 0) return CS_OK;
-  hipLaunchKernelGGL(cs_history_enqueue_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(cs_history_enqueue_kernel<T>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                      ring + (int64_t)new_tail * n, X, n, avail, chains, was_full);
   CS_HIP(hipGetLastError());
   return CS_OK;
+}
+
+extern "C" int cs_history_enqueue(float* ring, int64_t* avail, int32_t hist_len, int32_t new_tail, int32_t was_full,
+                                  const float* X, int64_t B, int32_t K, int32_t D, void* stream) {
+  return history_enqueue<float>(ring, avail, hist_len, new_tail, was_full, X, B, K, D, stream);
+}
+
+extern "C" int cs_history_enqueue_u8(uint8_t* ring, int64_t* avail, int32_t hist_len, int32_t new_tail, int32_t was_full,
+                                     const float* X, int64_t B, int32_t K, int32_t D, void* stream) {
+  return history_enqueue<uint8_t>(ring, avail, hist_len, new_tail, was_full, X, B, K, D, stream);
 }
 
 extern "C" int cs_history_set_available(int64_t* avail, const uint8_t* mask, int64_t chains, int64_t len, void* stream) {

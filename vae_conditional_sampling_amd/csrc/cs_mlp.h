@@ -50,6 +50,7 @@ struct CsMlpArgs {
   const float* in;
   int64_t in_stride;
   const int64_t* in_off;
+  int in_u8;  // 1: `in` points to uint8_t rows (0 / 1 values, element offsets in in_off); layer programs only
   // RAW output [rows,out_dim]
   float* out;
   // ENC: rows are (b,k), k < K; q[(b*Kp+k)*2*Zd + {0,Zd} + z]

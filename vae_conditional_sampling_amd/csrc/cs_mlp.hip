@@ -95,6 +95,7 @@ int cs_mlp_launch(const CsMlpArgs& a_in, hipStream_t stream) {
   a.dbg = g_trace;
   if (a.rows <= 0) return CS_OK;
   if (a.net.prog) return cs_prog_launch(a, stream);
+  CS_REQUIRE(!a.in_u8, "uint8 input rows (binary history ring) need a layer-program network");
   cs_split_cfg();
   const int arith = a.net.arith >= 0 ? a.net.arith : cs_mlp_arith();
   const int waves16 = g_split16_waves ? g_split16_waves : (a.rows <= 20480 ? 4 : 8);

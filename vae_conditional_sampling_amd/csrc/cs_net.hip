@@ -971,13 +971,14 @@ __global__ void __launch_bounds__(256) cs_resize_kernel(const float* in, float* 
 // stage-in / finish kernels (rows are global row indices row0 + local)
 // ----------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) cs_gather_rows_kernel(const float* in, int64_t in_stride, const int64_t* in_off,
-                                                             int64_t row0, int64_t rows, int dim, float* out) {
+                                                             int64_t row0, int64_t rows, int dim, float* out, int in_u8) {
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (idx >= rows * dim) return;
   const int64_t r = idx / dim;
   const int c = (int)(idx - r * dim);
   const int64_t row = row0 + r;
-  out[idx] = in[(in_off ? in_off[row] : row * in_stride) + c];
+  const int64_t e = (in_off ? in_off[row] : row * in_stride) + c;
+  out[idx] = in_u8 ? (float)((const uint8_t*)in)[e] : in[e];
 }
 
 // Z = loc + scale * eps (or the override row); one thread per 4 latent dimensions.  Beta
@@ -1534,11 +1535,11 @@ int cs_prog_launch(const CsMlpArgs& a, hipStream_t stream) {
     if (a.mode == CS_MLP_DEC && a.in == nullptr) {
       if (int rc = cs_dec_stage_launch(a, row0, rows, stream)) return rc;
       input = a.Z + row0 * a.Zd;
-    } else if (a.in_off == nullptr && a.in_stride == p->in_dim) {
+    } else if (a.in_off == nullptr && a.in_stride == p->in_dim && !a.in_u8) {
       input = a.in + row0 * p->in_dim;
     } else {
       hipLaunchKernelGGL(cs_gather_rows_kernel, dim3(blocks_for(rows * p->in_dim)), dim3(256), 0, stream, a.in,
-                         a.in_stride, a.in_off, row0, rows, p->in_dim, buf[CS_NET_BUF_IN]);
+                         a.in_stride, a.in_off, row0, rows, p->in_dim, buf[CS_NET_BUF_IN], a.in_u8);
       input = buf[CS_NET_BUF_IN];
     }
     float* raw = a.mode == CS_MLP_RAW ? a.out + row0 * p->out_dim : buf[CS_NET_BUF_OUT];

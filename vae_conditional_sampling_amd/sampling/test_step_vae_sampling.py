@@ -495,7 +495,7 @@ class TestVAELatentAdaptiveImportanceResampling(TestVAESamplerBase):
         history = None
         if hp.num_historical_proposals is not None:   # :1866-1870
             history = ImputationHistoryQueue(max_history_length=hp.imputation_history_length, batch_shape=X.shape,
-                                             dtype=torch.float32, device=X.device)
+                                             dtype=torch.bool if _check_if_bool(X) else torch.float32, device=X.device)
         clip_min = clip_max = None
         if hp.clip_imputations:
             X_temp = X[:, 0].clone()
@@ -1051,7 +1051,8 @@ class TestVAEAdaptiveCollapsedMetropolisWithinGibbs(_MetropolisWithinGibbsCommon
         bool_data = _check_if_bool(X)
         history = ImputationHistoryQueue_with_restrictedavailability(
             max_history_length=self.max_iterations, batch_shape=X.shape,
-            dtype=X.dtype if not bool_data else torch.bool, device=dev)
+            dtype=X.dtype if not bool_data else torch.bool, device=dev,
+            compact=isinstance(model.var_latent_network.packed(), _lib.PackedProgram))
         self.history = history
 
         def enqueue(Xw, last):
@@ -1088,7 +1089,7 @@ class TestVAEAdaptiveCollapsedMetropolisWithinGibbs(_MetropolisWithinGibbsCommon
         def cfg_now(flags=flags):
             return _lib.cs_acmwg_cfg(B, K, D, Zd, latent, gen_dist, history.max_history_length,
                                      max(history.tail_idx, 0), int(history.full), flags,
-                                     float(hp.prior_mixture_probability), temp, anneal)
+                                     float(hp.prior_mixture_probability), temp, anneal, int(history.u8))
 
         if hp.warmup_method == 'pseudo_gibbs':
             self._state_after_pseudo_gibbs(st, X, M8, joint=ablation)

@@ -29,7 +29,10 @@ class ImputationHistoryQueue(object):
         self.full = False
         self.batch_shape = tuple(batch_shape)
         B, K, D = self.batch_shape
-        self.history_queue = torch.empty((self.max_history_length, B, K, D), dtype=torch.float32, device=device)
+        # dtype bool (the reference's queue for binary data, which stores X.bool()): a uint8 ring holding x != 0
+        self.u8 = dtype == torch.bool
+        self.history_queue = torch.empty((self.max_history_length, B, K, D),
+                                         dtype=torch.uint8 if self.u8 else torch.float32, device=device)
 
     def __len__(self):
         assert self.tail_idx > -1, 'Queue is empty.'
@@ -44,8 +47,9 @@ class ImputationHistoryQueue(object):
         B, K, D = self.batch_shape
         X = X.to(self.history_queue.device, torch.float32).contiguous()
         self._increment_tail()
-        _lib.check(_lib.lib().cs_history_enqueue(_lib.ptr(self.history_queue), None, self.max_history_length,
-                                                 self.tail_idx, 0, _lib.ptr(X), B, K, D, _lib.current_stream()))
+        fn = _lib.lib().cs_history_enqueue_u8 if self.u8 else _lib.lib().cs_history_enqueue
+        _lib.check(fn(_lib.ptr(self.history_queue), None, self.max_history_length, self.tail_idx, 0, _lib.ptr(X), B, K, D,
+                      _lib.current_stream()))
 
     def window_size(self, num_historical_proposals):
         """Exclusive bound of the per-window integer draws (utils.py:33-36)."""
@@ -68,8 +72,9 @@ class ImputationHistoryQueue(object):
         cop = i32(*[int(c) for c in chain_of_proposal]) if chain_of_proposal is not None else None
         coe = chain_of_example.to(X.device, torch.int64).contiguous() if chain_of_example is not None else None
         rng = rng if rng is not None else _lib.make_rng(0)
-        _lib.check(_lib.lib().cs_history_concat(_lib.ptr(X), _lib.ptr(self.history_queue), B, K, D, H, i32(*slots), cop,
-                                                _lib.ptr(coe), C.byref(rng), _lib.ptr(Xc), _lib.current_stream()))
+        fn = _lib.lib().cs_history_concat_u8 if self.u8 else _lib.lib().cs_history_concat
+        _lib.check(fn(_lib.ptr(X), _lib.ptr(self.history_queue), B, K, D, H, i32(*slots), cop, _lib.ptr(coe), C.byref(rng),
+                      _lib.ptr(Xc), _lib.current_stream()))
         return Xc
 
 
@@ -91,17 +96,22 @@ def glr_history_chain_idx(K, num_historical_proposals, glr_cluster_size):
 
 
 class ImputationHistoryQueue_with_restrictedavailability(object):
-    def __init__(self, max_history_length, batch_shape, dtype=torch.float32, device="cuda"):
+    def __init__(self, max_history_length, batch_shape, dtype=torch.float32, device="cuda", compact=True):
         if dtype not in (torch.float32, torch.bool):
             raise NotImplementedError(f"history dtype {dtype}")
         self.max_history_length = int(max_history_length)
         self.tail_idx = -1
         self.full = False
-        self.bool_data = dtype == torch.bool  # values are 0/1; the ring itself is float32
+        self.bool_data = dtype == torch.bool  # values are 0/1
+        # dtype bool (the reference stores X.bool(), test_step_vae_sampling.py:1537-1541): a uint8 ring holding x != 0,
+        # a quarter of the float ring (Omniglot, B=200, K=5, T=5000: 3.9 GB instead of 15.7).  compact=False keeps
+        # the float ring: the fused MLP encoder reads its input rows as float32 straight from the ring.
+        self.u8 = self.bool_data and compact
         self.batch_shape = tuple(batch_shape)
         B, K, D = self.batch_shape
         # t b k d
-        self.history_queue = torch.empty((self.max_history_length, B, K, D), dtype=torch.float32, device=device)
+        self.history_queue = torch.empty((self.max_history_length, B, K, D),
+                                         dtype=torch.uint8 if self.u8 else torch.float32, device=device)
         # b k
         self.available_timesteps = torch.zeros((B, K), dtype=torch.int64, device=device)
 
@@ -131,9 +141,9 @@ class ImputationHistoryQueue_with_restrictedavailability(object):
         B, K, D = self.batch_shape
         X = X.to(self.history_queue.device, torch.float32).contiguous()
         new_tail, was_full = self.advance()
-        _lib.check(_lib.lib().cs_history_enqueue(_lib.ptr(self.history_queue), _lib.ptr(self.available_timesteps),
-                                                 self.max_history_length, new_tail, int(was_full), _lib.ptr(X),
-                                                 B, K, D, _lib.current_stream()))
+        fn = _lib.lib().cs_history_enqueue_u8 if self.u8 else _lib.lib().cs_history_enqueue
+        _lib.check(fn(_lib.ptr(self.history_queue), _lib.ptr(self.available_timesteps), self.max_history_length, new_tail,
+                      int(was_full), _lib.ptr(X), B, K, D, _lib.current_stream()))
 
     def slots_from_draws(self, r):
         """Ring slot of integer draws r[B,K] in [0, max(avail,1)) (utils.py:225-232)."""

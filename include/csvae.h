@@ -39,6 +39,16 @@ extern "C" {
 #define CS_DIST_NORMAL_WITH_EPS 1 /* scale = softplus(raw) + 1e-8     */
 #define CS_DIST_BERN 2            /* logits                           */
 #define CS_DIST_BETA 3            /* latent only: (alpha, beta) = softplus(raw halves); vae.py:239-243 */
+/* Generator (likelihood) families of the LAIR path beyond those (vae.py:220-229, 244-247): layer-program decoders
+ * only, AC-MWG entry points reject them.
+ *   Student-t: the decoder outputs (df_raw | loc | scale_raw), D each; `gen` holds [loc | scale | df] with
+ *   df = softplus(df_raw), scale = softplus(scale_raw) (+ 0.25 for STUDENTT_EPS22).  A sample is
+ *   loc + scale * n * rsqrt(c / df), n standard normal (eps_x), c chi-square(df) (chi2_x) as torch's StudentT.rsample.
+ *   Logit-normal: (loc | scale_raw), scale = softplus + 1e-8; a sample is sigmoid(loc + scale * n) clamped to
+ *   [FLT_MIN, 1 - FLT_EPSILON], the density torch's SigmoidTransform of a Normal gives. */
+#define CS_DIST_STUDENTT 4
+#define CS_DIST_STUDENTT_EPS22 5
+#define CS_DIST_LOGITNORMAL_WITH_EPS 6
 /* prior over the latents (VAE.get_prior, vae.py:158-164) */
 #define CS_PRIOR_STD_NORMAL 0
 #define CS_PRIOR_UNIFORM 1        /* Uniform(0, 1 + 1e-8): use_uniform_prior (toy configuration) */
@@ -167,7 +177,8 @@ typedef struct {
   /* outputs / workspace (required unless marked optional) */
   float* q;            /* [B,K',2,Zd] proposal loc and scale (after softplus) */
   float* Z;            /* [I,B,K',Zd] proposals */
-  float* gen;          /* [I,B,K',2,D] generator mean and scale; Bernoulli: [I,B,K',D] logits */
+  float* gen;          /* [I,B,K',2,D] generator mean and scale; Bernoulli: [I,B,K',D] logits; Student-t: [I,B,K',3,D]
+                          loc, scale, df */
   float* gen_ll;       /* [I,B,K'] masked log-likelihood of X under each proposal */
   float* log_w;        /* [I,B,K'] */
   float* norm_log_w;   /* [B,I*K'] (gr '(i k)'; glr '(g i c)'; lr '(k i)'; ir: the log-weights, '(i k)') */
@@ -185,6 +196,7 @@ typedef struct {
   const float* e_res;
   const float* e_res2;
   float* X_out; /* optional [B,K_impute,D]: the new imputations go here instead of in place */
+  const float* chi2_x; /* Student-t generators: injected chi-square(df) draws [B,K,D] beside eps_x (NULL -> counter RNG) */
 } cs_lair_bufs;
 
 /* Historical proposals of LAIR (ImputationHistoryQueue.sample_history /
@@ -357,7 +369,7 @@ int cs_imputation_errors(const float* X, const float* X_true, const uint8_t* M, 
 int cs_latent_wasserstein(const float* q_imp, const float* q_true, int64_t B, int32_t K, int32_t Zd, float* out,
                           void* stream);
 
-/* gen[rows,2,D] (mean, scale) or [rows,D] (Bernoulli logits) = generator parameterisation of
+/* gen[rows,2,D] (mean, scale), [rows,D] (Bernoulli logits) or [rows,3,D] (Student-t: loc, scale, df) = generator parameterisation of
  * generator_network(Z[rows,Zd]) (vae.py:171-172,203-256). */
 int cs_decode_params(const cs_mlp_t* dec, const float* Z, int64_t rows, int32_t gen_dist, float* gen, void* stream);
 /* x_m ~ p(x | gen) and X = X*M + x_m*(1-M) for rows (b,k), in place: pseudo_gibbs_iteration
@@ -372,6 +384,10 @@ int cs_decode_params(const cs_mlp_t* dec, const float* Z, int64_t rows, int32_t 
 int cs_sample_impute(const float* gen, int32_t gen_dist, const float* eps, const cs_rng* rng, uint32_t stream_id,
                      float* X, const uint8_t* M, int64_t B, int32_t K, int32_t D, const float* clip_min,
                      const float* clip_max, int32_t flags, void* stream);
+/* The same with the second injected draw of the Student-t generators (chi2[B*K,D] chi-square(df) draws, or NULL). */
+int cs_sample_impute2(const float* gen, int32_t gen_dist, const float* eps, const float* chi2, const cs_rng* rng,
+                      uint32_t stream_id, float* X, const uint8_t* M, int64_t B, int32_t K, int32_t D,
+                      const float* clip_min, const float* clip_max, int32_t flags, void* stream);
 
 /* LAIR final resampling (test_step_vae_sampling.py:1998-2009): logw[TI,B,K'] and
  * Zprops[TI,B,K',Zd] hold the proposals of all TI = T*I stored iterations; per example a

@@ -109,17 +109,23 @@ def make_inputs(B, K, D, seed, miss=0.5):
 @selectable
 def case_lair(ns, name, *, B, K, R, I, D, Zd, H, nb_enc, nb_dec, seed, scheme="gr",
               weighting="dmis", method="multinomial", cluster=None, resampled_latents=False,
-              iters=2, temperature=None, anneal=None, latent_dist="normal_with_eps", norm=None):
+              iters=2, temperature=None, anneal=None, latent_dist="normal_with_eps", norm=None,
+              gen_dist="normal_with_eps"):
+    studentt = gen_dist in ("studentt", "studentt_with_eps22")
     enc = O.make_resfc_weights(D, 2 * Zd, nb_enc, H, seed, norm=norm)
-    dec = O.make_resfc_weights(Zd, 2 * D, nb_dec, H, seed + 1, norm=norm)
-    vae = ref_vae(ns, enc, dec, latent_dist=latent_dist)
+    dec = O.make_resfc_weights(Zd, (3 if studentt else 2) * D, nb_dec, H, seed + 1, norm=norm)
+    if studentt:  # degrees of freedom around 5: with the df < 1 of a zero-centred raw output one sample in a few hundred
+        dec["bf"][:D] += 5.0  # is beyond 1e6 and the next iteration's encoder overflows
+    vae = ref_vae(ns, enc, dec, latent_dist=latent_dist, gen_dist=gen_dist)
     X, M = make_inputs(B, K, D, seed + 2)
+    if gen_dist == "logitnormal_with_eps":  # data of the open unit interval
+        X = torch.sigmoid(X)
     fx = dict(flat_weights("enc", enc)); fx.update(flat_weights("dec", dec))
     fx.update(X0=X.numpy(), M=M.numpy(),
               cfg=np.array([B, K, R, I, D, Zd, H, cluster or 0, iters], dtype=np.int64),
               scheme=np.array(scheme), weighting=np.array(weighting), method=np.array(method),
               resampled_latents=np.array(resampled_latents), temperature=np.float64(temperature or 0.0),
-              anneal=np.array(anneal or ""), latent_dist=np.array(latent_dist))
+              anneal=np.array(anneal or ""), latent_dist=np.array(latent_dist), gen_dist=np.array(gen_dist))
     tape = DrawTape(seed + 3)
     Xr = X.clone()
     for t in range(iters):
@@ -135,16 +141,18 @@ def case_lair(ns, name, *, B, K, R, I, D, Zd, H, nb_enc, nb_dec, seed, scheme="g
         res_kind = "multinomial" if method == "multinomial" else "rand"
         if method == "multinomial" and scheme in ("lr", "ir"):
             res_kind = "exponential"   # one index per chain: ATen's single-sample multinomial
-        expect = ["normal", res_kind] + ([res_kind] if resampled_latents else []) + ["normal"]
+        expect = ["normal", res_kind] + ([res_kind] if resampled_latents else []) + ["normal"] + (["std_gamma"] if studentt else [])
         assert kinds == expect, kinds
         draws = {"eps_z": torch.from_numpy(ent[0][1]), "u_res": torch.from_numpy(ent[1][1]),
-                 "eps_x": torch.from_numpy(ent[-1][1])}
+                 "eps_x": torch.from_numpy(ent[-2 if studentt else -1][1])}
+        if studentt:  # Chi2.rsample = Gamma(df / 2, rate 0.5).rsample: _standard_gamma / 0.5, clamped to tiny
+            draws["chi2_x"] = (torch.from_numpy(ent[-1][1]) / 0.5).clamp(min=torch.finfo(torch.float32).tiny)
         if resampled_latents:
             draws["u_res2"] = torch.from_numpy(ent[2][1])
         o = O.lair_iteration(enc, dec, Xr, M, draws, num_imp_samples=I, weighting=weighting,
                              resampling_scheme=scheme, resampling_method=method,
                              glr_cluster_size=cluster, num_prior_replenish_proposals=R,
-                             return_resampled_latents=resampled_latents, latent_dist=latent_dist,
+                             return_resampled_latents=resampled_latents, latent_dist=latent_dist, gen_dist=gen_dist,
                              var_proposal_temperature=temperature, var_proposal_anneal_type_to_prior=anneal)
         close(o["X_new"], ret[0], "X_new"); close(o["ess"], ret[1], "ess")
         close(o["transformed_ess"], ret[2], "tess"); close(o["perplexity"], ret[3], "perplexity")
@@ -156,7 +164,9 @@ def case_lair(ns, name, *, B, K, R, I, D, Zd, H, nb_enc, nb_dec, seed, scheme="g
         if resampled_latents:
             close(o["latents_resampled"][:, :K] if False else o["latents_resampled"], ret[9], "latents_resampled")
         # the reference does not return indices: recover them from its outputs for the fixture
-        fx.update({f"t{t}_eps_z": ent[0][1], f"t{t}_u_res": ent[1][1], f"t{t}_eps_x": ent[-1][1],
+        if studentt:
+            fx[f"t{t}_chi2_x"] = draws["chi2_x"].numpy()
+        fx.update({f"t{t}_eps_z": ent[0][1], f"t{t}_u_res": ent[1][1], f"t{t}_eps_x": draws["eps_x"].numpy(),
                    f"t{t}_X_new": ret[0].numpy(), f"t{t}_ess": ret[1].numpy(),
                    f"t{t}_perplexity": ret[3].numpy(), f"t{t}_norm_log_weights": ret[5].numpy(),
                    f"t{t}_Z_imp": ret[6].numpy(), f"t{t}_log_weights": ret[7].numpy(),
@@ -467,6 +477,13 @@ def main():
               scheme="glr", weighting="dmis_within_groups", cluster=5)
     case_lair(ns, "lair_miniboone_shape", B=3, K=4, R=1, I=1, D=43, Zd=32, H=256, nb_enc=5, nb_dec=2, seed=606,
               iters=1)
+    # likelihood families no configuration uses (irwg/models/vae.py:220-229, 244-247)
+    case_lair(ns, "lair_gen_studentt", B=5, K=4, R=1, I=1, D=11, Zd=5, H=64, nb_enc=1, nb_dec=1, seed=811,
+              gen_dist="studentt")
+    case_lair(ns, "lair_gen_studentt_eps22", B=4, K=3, R=2, I=2, D=9, Zd=4, H=64, nb_enc=1, nb_dec=2, seed=812,
+              gen_dist="studentt_with_eps22")
+    case_lair(ns, "lair_gen_logitnormal", B=5, K=4, R=1, I=1, D=10, Zd=5, H=64, nb_enc=1, nb_dec=1, seed=813,
+              gen_dist="logitnormal_with_eps")
     case_acmwg(ns, "acmwg_irwg_warmup", B=3, K=5, D=9, Zd=4, H=64, seed=707, warmup="irwg", W=2, T=12, p=0.3,
                nkpc=4, cluster=5, R=5)
     # the MiniBooNE AC-MWG configuration (configs/uci_miniboone/sampling_u50/..k5_mwgm_usehistrestricted_005prior_

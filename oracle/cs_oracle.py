@@ -174,19 +174,66 @@ def bernoulli_log_prob(x, logits):
     return -F.binary_cross_entropy_with_logits(logits, x, reduction="none")
 
 
+def studentt_params(params, dist):
+    """'... (3 d) -> df, loc, scale' (vae.py:220-229): df = softplus(raw), scale = softplus(raw) (+ 2^-2 for
+    studentt_with_eps22)."""
+    d = params.shape[-1] // 3
+    df, loc, scale = F.softplus(params[..., :d]), params[..., d:2 * d], F.softplus(params[..., 2 * d:])
+    if dist == "studentt_with_eps22":
+        scale = scale + 2 ** -2
+    return df, loc, scale
+
+
+def studentt_log_prob(x, df, loc, scale):
+    """torch.distributions.StudentT.log_prob"""
+    y = (x - loc) / scale
+    Z = (scale.log() + 0.5 * df.log() + 0.5 * math.log(math.pi) + torch.lgamma(0.5 * df) - torch.lgamma(0.5 * (df + 1.)))
+    return -0.5 * (df + 1.) * torch.log1p(y ** 2. / df) - Z
+
+
+def logitnormal_params(params):
+    """vae.py:244-247"""
+    d = params.shape[-1] // 2
+    return params[..., :d], F.softplus(params[..., d:]) + EPSILON
+
+
+def logitnormal_log_prob(v, loc, scale):
+    """LogitNormal (irwg/utils/logit_normal.py) = TransformedDistribution(Normal, SigmoidTransform).log_prob:
+    u = SigmoidTransform.inv(v) with v clamped to [tiny, 1 - eps]; 0 - log|dv/du| + Normal.log_prob(u),
+    log|dv/du| = -softplus(-u) - softplus(u)."""
+    finfo = torch.finfo(v.dtype)
+    y = v.clamp(min=finfo.tiny, max=1. - finfo.eps)
+    u = y.log() - (-y).log1p()
+    ladj = -F.softplus(-u) - F.softplus(u)
+    return (0.0 - ladj) + normal_log_prob(u, loc, scale)
+
+
 def gen_log_prob(x, params, dist):
     if dist == "bern":
         return bernoulli_log_prob(x, params)
+    if dist in ("studentt", "studentt_with_eps22"):
+        return studentt_log_prob(x, *studentt_params(params, dist))
+    if dist == "logitnormal_with_eps":
+        return logitnormal_log_prob(x, *logitnormal_params(params))
     loc, scale = split_loc_scale(params, dist)
     return normal_log_prob(x, loc, scale)
 
 
-def gen_sample(params, dist, draw):
+def gen_sample(params, dist, draw, draw2=None):
     """Sample of the generator distribution from an injected draw: standard-normal eps for
     the Normal families (torch.normal(loc, scale) == loc + scale*eps bitwise on CPU),
-    float32 uniform u for Bernoulli (torch.bernoulli(p) == (u < p))."""
+    float32 uniform u for Bernoulli (torch.bernoulli(p) == (u < p)).  Student-t (StudentT.rsample):
+    loc + scale * (n * rsqrt(c / df)) from the standard normal n = draw and the chi-square(df) draw c = draw2.
+    Logit-normal: the clipped sigmoid of the Normal sample (SigmoidTransform._call)."""
     if dist == "bern":
         return (draw < torch.sigmoid(params)).to(params.dtype)
+    if dist in ("studentt", "studentt_with_eps22"):
+        df, loc, scale = studentt_params(params, dist)
+        return loc + scale * (draw * torch.rsqrt(draw2 / df))
+    if dist == "logitnormal_with_eps":
+        loc, scale = logitnormal_params(params)
+        finfo = torch.finfo(params.dtype)
+        return torch.clamp(torch.sigmoid(loc + scale * draw), min=finfo.tiny, max=1. - finfo.eps)
     loc, scale = split_loc_scale(params, dist)
     return loc + scale * draw
 
@@ -605,7 +652,7 @@ def _lair_finish(out, X, Mf, Z, gen_params, log_w, gl, pl, ql, q_loc, q_scale, v
         latents_resampled = gather_gr(Z, idx2)
         out["idx2"] = idx2
     mis_params = mis_params[:, :K]
-    X_m = gen_sample(mis_params, gen_dist, draws["eps_x"])
+    X_m = gen_sample(mis_params, gen_dist, draws["eps_x"], draws.get("chi2_x"))
     X_new = X * Mf + X_m * (~Mf)
 
     lwr = log_w.permute(1, 0, 2).reshape(B, I * Kp)

@@ -229,12 +229,29 @@ class DrawTape:
             tape._rec("randint", out)
             return out
 
+        # StudentT.rsample: X = _standard_normal(...), Z = Chi2(df).rsample() = _standard_gamma(df / 2) / 0.5
+        import torch.distributions.gamma as _gamma_mod
+        import torch.distributions.studentT as _studentt_mod
+        orig_sn, orig_sg = _studentt_mod._standard_normal, _gamma_mod._standard_gamma
+
+        def standard_normal(shape, dtype, device):
+            eps = orig["randn"](tuple(shape), generator=tape.gen, dtype=torch.float32)
+            tape._rec("normal", eps)
+            return eps.to(device)
+
+        def standard_gamma(concentration):
+            out = torch._standard_gamma(concentration, tape.gen)
+            tape._rec("std_gamma", out)
+            return out
+
+        _studentt_mod._standard_normal, _gamma_mod._standard_gamma = standard_normal, standard_gamma
         torch.normal, torch.randn, torch.multinomial = normal, randn, multinomial
         torch.rand, torch.rand_like, torch.bernoulli, torch.randint = rand, rand_like, bernoulli, randint
         torch._sample_dirichlet = sample_dirichlet
         try:
             yield self
         finally:
+            _studentt_mod._standard_normal, _gamma_mod._standard_gamma = orig_sn, orig_sg
             torch.normal, torch.randn, torch.multinomial = orig["normal"], orig["randn"], orig["multinomial"]
             torch.rand, torch.rand_like, torch.bernoulli = orig["rand"], orig["rand_like"], orig["bernoulli"]
             torch.randint = orig["randint"]

@@ -23,7 +23,9 @@ mlp_arith = arith_fixture()
 LAIR_CASES = ["lair_gr_mult_small", "lair_gr_mult_i2_lat", "lair_gr_mult_noreplenish", "lair_gr_syst",
               "lair_glr_groups", "lair_miniboone_shape", "lair_tempered_annealed", "lair_annealed_025_normal",
               "lair_tempered", "lair_lr_mult", "lair_lr_syst", "lair_ir_mult", "lair_ir_mult_i6", "lair_ir_syst",
-              "lair_layernorm_nets", "lair_batchnorm_nets"]
+              "lair_layernorm_nets", "lair_batchnorm_nets",
+              # Student-t and logit-normal likelihoods (irwg/models/vae.py:220-229, 244-247)
+              "lair_gen_studentt", "lair_gen_studentt_eps22", "lair_gen_logitnormal"]
 
 
 @pytest.fixture(scope="module")
@@ -68,7 +70,9 @@ def test_lair_iteration_matches_reference_golden(name):
     fx = load_golden(name)
     B, K, R, I, D, Zd, H, cluster, iters = [int(v) for v in fx["cfg"]]
     latent_dist = str(fx["latent_dist"])
-    model = make_model(weights_from_fixture(fx, "enc"), weights_from_fixture(fx, "dec"), latent_dist=latent_dist)
+    gen_dist = str(fx["gen_dist"]) if "gen_dist" in fx else "normal_with_eps"
+    model = make_model(weights_from_fixture(fx, "enc"), weights_from_fixture(fx, "dec"), latent_dist=latent_dist,
+                       gen_dist=gen_dist)
     scheme, weighting, method = str(fx["scheme"]), str(fx["weighting"]), str(fx["method"])
     want_lat = bool(fx["resampled_latents"])
     temperature, anneal = float(fx["temperature"]) or None, str(fx["anneal"]) or None
@@ -79,6 +83,8 @@ def test_lair_iteration_matches_reference_golden(name):
                  "eps_x": torch.from_numpy(fx[f"t{t}_eps_x"])}
         if want_lat:
             draws["u_res2"] = torch.from_numpy(fx[f"t{t}_u_res2"])
+        if f"t{t}_chi2_x" in fx:  # Student-t generator: chi-square draws beside the normals
+            draws["chi2_x"] = torch.from_numpy(fx[f"t{t}_chi2_x"])
         out = importance_resampling_gibbs_iteration(
             model, X, M, I, glr_cluster_size=cluster or None, weighting=weighting, resampling_method=method,
             resampling_scheme=scheme, num_prior_replenish_proposals=R, return_resampled_latents=want_lat,

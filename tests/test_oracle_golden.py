@@ -16,7 +16,9 @@ from tests.helpers import assert_close, load_golden, weights_from_fixture
 LAIR_CASES = ["lair_gr_mult_small", "lair_gr_mult_i2_lat", "lair_gr_mult_noreplenish", "lair_gr_syst",
               "lair_glr_groups", "lair_miniboone_shape", "lair_tempered_annealed", "lair_annealed_025_normal",
               "lair_tempered", "lair_lr_mult", "lair_lr_syst", "lair_ir_mult", "lair_ir_mult_i6", "lair_ir_syst",
-              "lair_layernorm_nets", "lair_batchnorm_nets"]
+              "lair_layernorm_nets", "lair_batchnorm_nets",
+              # Student-t and logit-normal likelihoods (irwg/models/vae.py:220-229, 244-247)
+              "lair_gen_studentt", "lair_gen_studentt_eps22", "lair_gen_logitnormal"]
 
 
 @pytest.mark.parametrize("name", LAIR_CASES)
@@ -30,7 +32,10 @@ def test_oracle_lair_iteration(name):
         draws = {k: torch.from_numpy(fx[f"t{t}_{k}"]) for k in ("eps_z", "u_res", "eps_x")}
         if want_lat:
             draws["u_res2"] = torch.from_numpy(fx[f"t{t}_u_res2"])
+        if f"t{t}_chi2_x" in fx:
+            draws["chi2_x"] = torch.from_numpy(fx[f"t{t}_chi2_x"])
         o = O.lair_iteration(enc, dec, X, M, draws, num_imp_samples=I, weighting=str(fx["weighting"]),
+                             gen_dist=str(fx["gen_dist"]) if "gen_dist" in fx else "normal_with_eps",
                              resampling_scheme=str(fx["scheme"]), resampling_method=str(fx["method"]),
                              glr_cluster_size=cluster or None, num_prior_replenish_proposals=R,
                              return_resampled_latents=want_lat, latent_dist=str(fx["latent_dist"]),

@@ -12,7 +12,14 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcsvae.so")
 
-CS_DIST = {"normal": 0, "normal_with_eps": 1, "bern": 2, "beta": 3}
+CS_DIST = {"normal": 0, "normal_with_eps": 1, "bern": 2, "beta": 3, "studentt": 4, "studentt_with_eps22": 5,
+           "logitnormal_with_eps": 6}
+# parameter vectors per dimension of a generator family (decoder output = GEN_NPARAMS * D, split likewise)
+GEN_NPARAMS = {"bern": 1, "studentt": 3, "studentt_with_eps22": 3}
+
+
+def gen_nparams(name):
+    return GEN_NPARAMS.get(name, 2)
 CS_PRIOR = {"std_normal": 0, "uniform": 1}
 CS_WEIGHTING = {"dmis": 0, "dmis_within_groups": 1, "smis": 2}
 CS_SCHEME = {"gr": 0, "glr": 1, "lr": 2, "ir": 3}
@@ -72,7 +79,7 @@ class cs_lair_cfg(C.Structure):
 
 _LAIR_BUF_FIELDS = ["X", "M", "eps_z", "u_res", "u_res2", "u_sys", "u_sys2", "eps_x", "q", "Z", "gen",
                     "gen_ll", "log_w", "norm_log_w", "idx", "ess", "tess", "perplexity",
-                    "latents_resampled", "idx2", "clip_min", "clip_max", "e_res", "e_res2", "X_out"]
+                    "latents_resampled", "idx2", "clip_min", "clip_max", "e_res", "e_res2", "X_out", "chi2_x"]
 
 
 class cs_lair_bufs(C.Structure):
@@ -157,6 +164,7 @@ def lib():
     L.cs_imputation_errors.argtypes = [vp, vp, vp, i64, i32, i32, vp, vp, vp]
     L.cs_latent_wasserstein.argtypes = [vp, vp, i64, i32, i32, vp, vp]
     L.cs_sample_impute.argtypes = [vp, i32, vp, C.POINTER(cs_rng), u32, vp, vp, i64, i32, i32, vp, vp, i32, vp]
+    L.cs_sample_impute2.argtypes = [vp, i32, vp, vp, C.POINTER(cs_rng), u32, vp, vp, i64, i32, i32, vp, vp, i32, vp]
     for fn in ("cs_rng_normal", "cs_rng_uniform", "cs_rng_uniform64"):
         getattr(L, fn).argtypes = [C.POINTER(cs_rng), u32, i64, i32, vp, vp]
     _lib = L

@@ -216,4 +216,44 @@ __device__ inline float cs_bernoulli_logpmf(float x, float l) {
   return -((1.0f - x) * l + fmaxf(-l, 0.0f) + cs_log1pf01(cs_expf(-fabsf(l))));
 }
 __device__ inline float cs_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + cs_expf(-x)); }
+
+// ---- generator families of the LAIR path beyond normal / Bernoulli (irwg/models/vae.py:220-229, 244-247) ----
+__host__ __device__ inline bool cs_dist_is_studentt(int d) { return d == CS_DIST_STUDENTT || d == CS_DIST_STUDENTT_EPS22; }
+// parameter vectors of D entries per row in `gen`
+__host__ __device__ inline int cs_gen_nparams(int d) { return d == CS_DIST_BERN ? 1 : (cs_dist_is_studentt(d) ? 3 : 2); }
+// torch.distributions.StudentT.log_prob
+__device__ inline float cs_studentt_logpdf(float x, float df, float loc, float scale) {
+  const float y = (x - loc) / scale;
+  const float Z = logf(scale) + 0.5f * logf(df) + 0.5f * 1.1447298858494002f + lgammaf(0.5f * df) - lgammaf(0.5f * (df + 1.0f));
+  return -0.5f * (df + 1.0f) * log1pf(y * y / df) - Z;
+}
+// LogitNormal = SigmoidTransform of Normal(loc, scale) (irwg/utils/logit_normal.py): log_prob(v) = Normal.log_prob(u) +
+// softplus(-u) + softplus(u) with u = logit(clamp(v, FLT_MIN, 1 - FLT_EPSILON))
+__device__ inline float cs_logitnormal_logpdf(float v, float loc, float scale) {
+  const float y = fminf(fmaxf(v, 1.17549435e-38f), 1.0f - 1.1920929e-7f);
+  const float u = logf(y) - log1pf(-y);
+  return cs_normal_logpdf(u, loc, scale) + cs_softplus(-u) + cs_softplus(u);
+}
+__device__ inline float cs_clipped_sigmoid(float x) {
+  return fminf(fmaxf(1.0f / (1.0f + expf(-x)), 1.17549435e-38f), 1.0f - 1.1920929e-7f);
+}
+// log p(x | parameters) of one dimension; p2 only for Student-t (df)
+__device__ inline float cs_gen_logpdf(int dist, float x, float p0, float p1, float p2) {
+  if (dist == CS_DIST_BERN) return cs_bernoulli_logpmf(x, p0);
+  if (cs_dist_is_studentt(dist)) return cs_studentt_logpdf(x, p2, p0, p1);
+  if (dist == CS_DIST_LOGITNORMAL_WITH_EPS) return cs_logitnormal_logpdf(x, p0, p1);
+  return cs_normal_logpdf(x, p0, p1);
+}
+// x ~ p(. | parameters) from a standard normal n (Bernoulli: a uniform) and, for Student-t, a chi-square(df) draw c
+__device__ inline float cs_gen_sample(int dist, float p0, float p1, float p2, float n, float c) {
+  if (dist == CS_DIST_BERN) return (n < cs_sigmoid(p0)) ? 1.0f : 0.0f;
+  if (cs_dist_is_studentt(dist)) return p0 + p1 * (n * rsqrtf(c / p2));
+  if (dist == CS_DIST_LOGITNORMAL_WITH_EPS) return cs_clipped_sigmoid(p0 + p1 * n);
+  return p0 + p1 * n;
+}
+// chi-square(df) from the counter RNG: 2 * Gamma(df / 2), drawn from the companion stream (stream | 16) of the
+// normal draws' stream; element e of (stream,row) owns its blocks [32e, 32e + 32)
+__device__ inline float cs_chi2_sample(const CsPhilox& p, uint32_t stream, int64_t row, uint32_t e, float df) {
+  return 2.0f * cs_gamma_sample(p, stream | 16u, row, 32u * e, 0.5f * df);
+}
 #endif

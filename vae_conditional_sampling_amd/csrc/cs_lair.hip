@@ -497,6 +497,9 @@ __global__ void __launch_bounds__(64) cs_lair_resample_kernel(const CsResampleAr
   CS_TICK();
   const int DQ = (D + 3) >> 2;
   const bool bern = a.cfg.gen_dist == CS_DIST_BERN;
+  const bool stt = cs_dist_is_studentt(a.cfg.gen_dist);
+  const bool other = a.cfg.gen_dist > CS_DIST_BERN;  // Student-t, logit-normal
+  const int np = cs_gen_nparams(a.cfg.gen_dist);
   const bool clip = a.b.clip_min || a.b.clip_max;
   const int Kimp = a.Kimp;
   for (int t = lane; t < ne * Kimp * DQ; t += 64) {
@@ -512,16 +515,19 @@ __global__ void __launch_bounds__(64) cs_lair_resample_kernel(const CsResampleAr
     // every input of the item is requested before anything is computed or stored: X is updated in
     // place, so a load placed after a store could not be moved ahead of it, and the item would pay
     // one memory round trip per dimension
-    const float* gr = a.b.gen + rho * (bern ? 1 : 2) * D;
+    const float* gr = a.b.gen + rho * np * D;
     typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));  // 16-byte access at 4-byte alignment
     const bool full = 4 * dq + 4 <= D;
     f32x4 g0 = {0.f, 0.f, 0.f, 0.f}, g1 = g0, xo = g0, dr = g0;
+    f32x4 g2 = {1.f, 1.f, 1.f, 1.f}, dc = g2;  // Student-t: degrees of freedom, chi-square draws
     float mk[4];
     if (full) {
       g0 = *(const f32x4_u*)(gr + 4 * dq);
       if (!bern) g1 = *(const f32x4_u*)(gr + D + 4 * dq);
+      if (stt) g2 = *(const f32x4_u*)(gr + 2 * D + 4 * dq);
       xo = *(const f32x4_u*)(xr + 4 * dq);
       if (a.b.eps_x) dr = *(const f32x4_u*)(a.b.eps_x + (be * Kimp + n) * D + 4 * dq);
+      if (stt && a.b.chi2_x) dc = *(const f32x4_u*)(a.b.chi2_x + (be * Kimp + n) * D + 4 * dq);
       uint32_t mb;
       __builtin_memcpy(&mb, mr + 4 * dq, 4);
 #pragma unroll
@@ -535,8 +541,10 @@ __global__ void __launch_bounds__(64) cs_lair_resample_kernel(const CsResampleAr
         if (in) {
           g0[r] = gr[d];
           if (!bern) g1[r] = gr[D + d];
+          if (stt) g2[r] = gr[2 * D + d];
           xo[r] = xr[d];
           if (a.b.eps_x) dr[r] = a.b.eps_x[(be * Kimp + n) * D + d];
+          if (stt && a.b.chi2_x) dc[r] = a.b.chi2_x[(be * Kimp + n) * D + d];
         }
       }
     }
@@ -550,12 +558,18 @@ __global__ void __launch_bounds__(64) cs_lair_resample_kernel(const CsResampleAr
         dr = cs_normal4(x);
       }
     }
+    if (stt && !a.b.chi2_x) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        dc[r] = cs_chi2_sample(a.rng, CS_STREAM_X, (a.rng.row_offset + be) * Kimp + n, (uint32_t)(4 * dq + r), g2[r]);
+    }
     f32x4 xn;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int d = 4 * dq + r;
       float xm;
       if (bern) xm = (dr[r] < cs_sigmoid(g0[r])) ? 1.0f : 0.0f;
+      else if (other) xm = cs_gen_sample(a.cfg.gen_dist, g0[r], g1[r], g2[r], dr[r], dc[r]);
       else xm = g0[r] + g1[r] * dr[r];
       xn[r] = xo[r] * mk[r] + xm * (1.0f - mk[r]);
       if (d < D) {
@@ -593,7 +607,9 @@ static int check_cfg(const cs_lair_cfg* c, const cs_lair_bufs* b) {
   CS_REQUIRE(c->latent_dist == CS_DIST_NORMAL || c->latent_dist == CS_DIST_NORMAL_WITH_EPS ||
                  c->latent_dist == CS_DIST_BETA,
              "latent distribution must be normal / normal_with_eps / beta");
-  CS_REQUIRE(c->gen_dist >= CS_DIST_NORMAL && c->gen_dist <= CS_DIST_BERN, "bad generator distribution");
+  CS_REQUIRE((c->gen_dist >= CS_DIST_NORMAL && c->gen_dist <= CS_DIST_BERN) || cs_dist_is_studentt(c->gen_dist) ||
+                 c->gen_dist == CS_DIST_LOGITNORMAL_WITH_EPS,
+             "bad generator distribution");
   CS_REQUIRE(c->prior == CS_PRIOR_STD_NORMAL || c->prior == CS_PRIOR_UNIFORM, "bad prior");
   return CS_OK;
 }
@@ -716,9 +732,8 @@ extern "C" int cs_lair_decode(const cs_mlp_t* dec, const cs_lair_cfg* c, const c
   if (int rc = check_cfg(c, b)) return rc;
   if (c->B == 0) return CS_OK;  // empty batch: nothing to do (its tensors have no storage)
   CS_REQUIRE(dec && b->X && b->M && b->q && b->Z && b->gen && b->gen_ll, "null argument");
-  const bool bern = c->gen_dist == CS_DIST_BERN;
-  CS_REQUIRE(dec->dev.in_dim == c->Zd && dec->dev.out_dim == (bern ? 1 : 2) * c->D &&
-                 dec->dev.split == (bern ? 1 : 2),
+  const int np = cs_gen_nparams(c->gen_dist);
+  CS_REQUIRE(dec->dev.in_dim == c->Zd && dec->dev.out_dim == np * c->D && dec->dev.split == np,
              "decoder shape does not match the configuration");
   CsMlpArgs a;
   std::memset(&a, 0, sizeof(a));
@@ -827,8 +842,7 @@ extern "C" int cs_lair_step(const cs_mlp_t* enc, const cs_mlp_t* dec, const cs_l
 extern "C" int cs_decode_params(const cs_mlp_t* dec, const float* Z, int64_t rows, int32_t gen_dist, float* gen,
                                 void* stream) {
   CS_REQUIRE(dec && Z && gen && rows >= 0, "bad argument");
-  const bool bern = gen_dist == CS_DIST_BERN;
-  CS_REQUIRE(dec->dev.split == (bern ? 1 : 2), "decoder output split does not match the distribution");
+  CS_REQUIRE(dec->dev.split == cs_gen_nparams(gen_dist), "decoder output split does not match the distribution");
   CsMlpArgs a;
   std::memset(&a, 0, sizeof(a));
   a.net = dec->dev;
@@ -845,7 +859,7 @@ extern "C" int cs_decode_params(const cs_mlp_t* dec, const float* Z, int64_t row
 }
 
 struct CsSampleImputeArgs {
-  const float* gen; int gen_dist; const float* eps; CsPhilox rng; uint32_t stream_id;
+  const float* gen; int gen_dist; const float* eps; const float* chi2; CsPhilox rng; uint32_t stream_id;
   float* X; const uint8_t* M; int64_t rows; int K, D; const float* clip_min; const float* clip_max;
   int flags;
 };
@@ -860,6 +874,16 @@ __global__ void __launch_bounds__(256) cs_sample_impute_kernel(const CsSampleImp
   if (a.gen_dist == CS_DIST_BERN) {
     const float u = a.eps ? a.eps[t] : cs_uniform_elem(a.rng, a.stream_id, a.rng.row_offset * a.K + row, d);
     xm = (u < cs_sigmoid(a.gen[t])) ? 1.0f : 0.0f;
+  } else if (a.gen_dist > CS_DIST_BERN) {  // Student-t, logit-normal
+    const int np = cs_gen_nparams(a.gen_dist);
+    const float* g = a.gen + row * np * a.D + d;
+    const float e = a.eps ? a.eps[t] : cs_normal_elem(a.rng, a.stream_id, a.rng.row_offset * a.K + row, d);
+    float df = 1.0f, c = 1.0f;
+    if (np == 3) {
+      df = g[2 * a.D];
+      c = a.chi2 ? a.chi2[t] : cs_chi2_sample(a.rng, a.stream_id, a.rng.row_offset * a.K + row, d, df);
+    }
+    xm = cs_gen_sample(a.gen_dist, g[0], g[a.D], df, e, c);
   } else {
     const float e = a.eps ? a.eps[t] : cs_normal_elem(a.rng, a.stream_id, a.rng.row_offset * a.K + row, d);
     xm = a.gen[row * 2 * a.D + d] + a.gen[row * 2 * a.D + a.D + d] * e;
@@ -882,11 +906,19 @@ __global__ void __launch_bounds__(256) cs_sample_impute_kernel(const CsSampleImp
 extern "C" int cs_sample_impute(const float* gen, int32_t gen_dist, const float* eps, const cs_rng* rng,
                                 uint32_t stream_id, float* X, const uint8_t* M, int64_t B, int32_t K, int32_t D,
                                 const float* clip_min, const float* clip_max, int32_t flags, void* stream) {
+  return cs_sample_impute2(gen, gen_dist, eps, nullptr, rng, stream_id, X, M, B, K, D, clip_min, clip_max, flags, stream);
+}
+
+extern "C" int cs_sample_impute2(const float* gen, int32_t gen_dist, const float* eps, const float* chi2, const cs_rng* rng,
+                                 uint32_t stream_id, float* X, const uint8_t* M, int64_t B, int32_t K, int32_t D,
+                                 const float* clip_min, const float* clip_max, int32_t flags, void* stream) {
   CS_REQUIRE(gen && X && B >= 0 && K >= 1 && D >= 1, "bad argument");
-  CS_REQUIRE(gen_dist >= CS_DIST_NORMAL && gen_dist <= CS_DIST_BERN, "bad generator distribution");
+  CS_REQUIRE((gen_dist >= CS_DIST_NORMAL && gen_dist <= CS_DIST_BERN) || cs_dist_is_studentt(gen_dist) ||
+                 gen_dist == CS_DIST_LOGITNORMAL_WITH_EPS,
+             "bad generator distribution");
   if (B == 0) return CS_OK;
   CsSampleImputeArgs a;
-  a.gen = gen; a.gen_dist = gen_dist; a.eps = eps; a.rng = cs_make_philox(rng); a.stream_id = stream_id;
+  a.gen = gen; a.gen_dist = gen_dist; a.eps = eps; a.chi2 = chi2; a.rng = cs_make_philox(rng); a.stream_id = stream_id;
   a.X = X; a.M = M; a.rows = B * K; a.K = K; a.D = D; a.clip_min = clip_min; a.clip_max = clip_max;
   a.flags = flags;
   const int64_t n = a.rows * D;
@@ -920,6 +952,7 @@ extern "C" int cs_lair_run(const cs_mlp_t* enc, const cs_mlp_t* dec, const cs_la
     cs_lair_bufs b = *b0;
     if (b.eps_z) b.eps_z += t * n_eps_z;
     if (b.eps_x) b.eps_x += t * n_eps_x;
+    if (b.chi2_x) b.chi2_x += t * n_eps_x;
     if (b.u_res) b.u_res += t * n_u_res;
     if (b.u_res2) b.u_res2 += t * n_u_res;
     if (b.u_sys) b.u_sys += t * n_u_sys;

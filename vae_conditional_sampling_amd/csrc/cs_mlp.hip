@@ -96,6 +96,9 @@ int cs_mlp_launch(const CsMlpArgs& a_in, hipStream_t stream) {
   if (a.rows <= 0) return CS_OK;
   if (a.net.prog) return cs_prog_launch(a, stream);
   CS_REQUIRE(!a.in_u8, "uint8 input rows (binary history ring) need a layer-program network");
+  if (a.mode == CS_MLP_DEC)
+    CS_REQUIRE(a.gen_dist >= CS_DIST_NORMAL && a.gen_dist <= CS_DIST_BERN,
+               "Student-t / logit-normal generators need a layer-program decoder");
   cs_split_cfg();
   const int arith = a.net.arith >= 0 ? a.net.arith : cs_mlp_arith();
   const int waves16 = g_split16_waves ? g_split16_waves : (a.rows <= 20480 ? 4 : 8);

@@ -1086,16 +1086,30 @@ __global__ void __launch_bounds__(64) cs_dec_finish_kernel(const CsMlpArgs a, co
       gr[d] = l;
       if (want_ll) ll += cs_bernoulli_logpmf(xr[d], l) * (mr ? (float)mr[d] : 1.0f);
     }
+  } else if (cs_dist_is_studentt(a.gen_dist)) {
+    // raw (df_raw | loc | scale_raw) -> gen [loc | scale | df] (vae.py:220-229)
+    const float* pr = raw + r * 3 * D;
+    float* gr = a.gen + row * 3 * D;
+    const float eps = a.gen_dist == CS_DIST_STUDENTT_EPS22 ? 0.25f : 0.0f;
+    for (int d = lane; d < D; d += 64) {
+      const float df = cs_softplus(pr[d]);
+      const float loc = pr[D + d];
+      const float sc = cs_softplus(pr[2 * D + d]) + eps;
+      gr[d] = loc;
+      gr[D + d] = sc;
+      gr[2 * D + d] = df;
+      if (want_ll) ll += cs_studentt_logpdf(xr[d], df, loc, sc) * (mr ? (float)mr[d] : 1.0f);
+    }
   } else {
     const float* pr = raw + r * 2 * D;
     float* gr = a.gen + row * 2 * D;
-    const float eps = a.gen_dist == CS_DIST_NORMAL_WITH_EPS ? 1e-8f : 0.0f;
+    const float eps = (a.gen_dist == CS_DIST_NORMAL_WITH_EPS || a.gen_dist == CS_DIST_LOGITNORMAL_WITH_EPS) ? 1e-8f : 0.0f;
     for (int d = lane; d < D; d += 64) {
       const float mean = pr[d];
       const float sc = cs_softplus(pr[D + d]) + eps;
       gr[d] = mean;
       gr[D + d] = sc;
-      if (want_ll) ll += cs_normal_logpdf(xr[d], mean, sc) * (mr ? (float)mr[d] : 1.0f);
+      if (want_ll) ll += cs_gen_logpdf(a.gen_dist, xr[d], mean, sc, 0.0f) * (mr ? (float)mr[d] : 1.0f);
     }
   }
   if (want_ll) {
@@ -1321,7 +1335,7 @@ extern "C" int cs_net_create(const cs_layer_desc* layers, int32_t n_layers, cons
   CS_REQUIRE(layers && blob && out, "null argument");
   CS_REQUIRE(n_layers >= 1 && n_layers <= 4096, "bad layer count");
   CS_REQUIRE(in_dim >= 1 && out_dim >= 1, "bad network dimensions");
-  CS_REQUIRE(out_split == 1 || out_split == 2, "out_split must be 1 or 2");
+  CS_REQUIRE(out_split >= 1 && out_split <= 3, "out_split must be 1, 2 or 3");
   CS_REQUIRE(out_dim % out_split == 0, "out_dim not divisible by out_split");
   CsProgram* p = new CsProgram();
   p->in_dim = in_dim;
@@ -1510,9 +1524,11 @@ int cs_prog_launch(const CsMlpArgs& a, hipStream_t stream) {
   int dev = 0;
   CS_HIP(hipGetDevice(&dev));
   CS_REQUIRE(dev == p->device, "network was created on another device");
-  if (a.mode == CS_MLP_DEC && a.gen_dist != CS_DIST_BERN)
-    CS_REQUIRE(a.net.split == 2 && a.net.out_dim == 2 * a.D, "generator output must be (mean | raw scale)");
-  if (a.mode == CS_MLP_DEC && a.gen_dist == CS_DIST_BERN) CS_REQUIRE(a.net.out_dim == a.D, "generator output must be D logits");
+  if (a.mode == CS_MLP_DEC) {
+    const int np = cs_gen_nparams(a.gen_dist);
+    CS_REQUIRE(a.net.out_dim == np * a.D && (np == 1 || a.net.split == np),
+               "generator output must be D logits, (mean | raw scale) or (raw df | loc | raw scale)");
+  }
   if (a.mode == CS_MLP_ENC) CS_REQUIRE(a.net.out_dim == 2 * a.Zd, "encoder output must be (loc | raw scale)");
 
   // workspace: [staged input | scratch 1..4 | raw output] per row, for a chunk of rows.  It only grows here when

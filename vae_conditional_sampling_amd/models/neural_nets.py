@@ -56,7 +56,8 @@ class ResidualFCNetwork(nn.Module):
         self.blocks = nn.ModuleList([_Block(residual_block_dim, use_batch_norm, use_layer_norm)
                                      for _ in range(num_residual_blocks)])
         self.final_layer = nn.Linear(residual_block_dim, output_dim)
-        self.out_split = 2  # (loc | raw scale); the VAE sets 1 for Bernoulli logits
+        self.out_split = 2  # (loc | raw scale); the VAE sets 1 for Bernoulli logits, 3 for Student-t
+        self.force_program = False  # True: run as a layer program even where the fused kernel would fit
         self._packed = None
         self._packed_key = None
         self._tensors = None
@@ -87,11 +88,13 @@ class ResidualFCNetwork(nn.Module):
         # expensive part), storage pointers and version counters detect .to() / load_state_dict / in-place edits
         if self._tensors is None:
             self._tensors = list(self.parameters()) + list(self.buffers())
-        key = (tuple((p.data_ptr(), p._version) for p in self._tensors), self.out_split, torch.cuda.current_device())
+        key = (tuple((p.data_ptr(), p._version) for p in self._tensors), self.out_split, torch.cuda.current_device(),
+               self.force_program)
         if self._packed is None or self._packed_key != key:
             w = self.weight_dict()
             half = self.output_dim // self.out_split
             if (self.residual_block_dim in (64, 128, 256) and self.input_dims <= 128 and not self.use_layer_norm
+                    and self.out_split in (1, 2) and not self.force_program
                     and half <= (64 if self.out_split == 2 else 128)):
                 self._packed = _lib.PackedMLP(w["W0"], w["b0"], w["blocks"], w["Wf"], w["bf"], self.out_split)
             else:

@@ -30,7 +30,10 @@ class DISTRIBUTION(Enum):
 
 
 _SUPPORTED_LATENT = (DISTRIBUTION.normal, DISTRIBUTION.normal_with_eps, DISTRIBUTION.beta)
-_SUPPORTED_GEN = (DISTRIBUTION.normal, DISTRIBUTION.normal_with_eps, DISTRIBUTION.bern)
+# Student-t and logit-normal likelihoods (vae.py:220-229, 244-247): LAIR path only, layer-program decoders
+_SUPPORTED_GEN = (DISTRIBUTION.normal, DISTRIBUTION.normal_with_eps, DISTRIBUTION.bern, DISTRIBUTION.studentt,
+                  DISTRIBUTION.studentt_with_eps22, DISTRIBUTION.logitnormal_with_eps)
+_PROGRAM_ONLY_GEN = (DISTRIBUTION.studentt, DISTRIBUTION.studentt_with_eps22, DISTRIBUTION.logitnormal_with_eps)
 
 
 def _as_distribution(d):
@@ -55,7 +58,10 @@ class VAE(nn.Module):
         self.generator_network = generator_network
         self.var_latent_network = var_latent_network
         if hasattr(generator_network, "out_split"):
-            generator_network.out_split = 1 if self.hparams.generator_distribution is DISTRIBUTION.bern else 2
+            from .. import _lib
+            generator_network.out_split = _lib.gen_nparams(self.hparams.generator_distribution.name)
+            if self.hparams.generator_distribution in _PROGRAM_ONLY_GEN and hasattr(generator_network, "force_program"):
+                generator_network.force_program = True   # the fused MLP kernel's epilogues do not know these families
         if hasattr(var_latent_network, "out_split"):
             var_latent_network.out_split = 2
         self.eval()
@@ -122,6 +128,16 @@ class VAE(nn.Module):
             a, b = self.split_params(params, 2)
             return torch.distributions.Beta(concentration1=torch.nn.functional.softplus(a),
                                             concentration0=torch.nn.functional.softplus(b), validate_args=validate_args)
+        if distribution in (DISTRIBUTION.studentt, DISTRIBUTION.studentt_with_eps22):
+            df_raw, loc, raw = self.split_params(params, 3)
+            scale = torch.nn.functional.softplus(raw) + (2 ** -2 if distribution is DISTRIBUTION.studentt_with_eps22 else 0.)
+            return torch.distributions.StudentT(df=torch.nn.functional.softplus(df_raw), loc=loc, scale=scale,
+                                                validate_args=validate_args)
+        if distribution is DISTRIBUTION.logitnormal_with_eps:
+            loc, raw = self.split_params(params, 2)
+            base = torch.distributions.Normal(loc, torch.nn.functional.softplus(raw) + EPSILON, validate_args=validate_args)
+            return torch.distributions.TransformedDistribution(base, torch.distributions.SigmoidTransform(),
+                                                               validate_args=validate_args)
         raise NotImplementedError(f"Method not implemented for {distribution = }")
 
     def sample(self, num_samples, rng=None, *, return_latents=False, draws=None):

@@ -24,7 +24,7 @@ class LairWorkspace:
         self.B, self.K, self.R, self.I = B, K, R, I
         self.Kp = K + R
         self.NS = slots or self.Kp   # output slots of the resampling (glr with a padded layout: more than K')
-        self.D = model.generator_network.output_dim // (1 if model.hparams.generator_distribution.name == "bern" else 2)
+        self.D = model.generator_network.output_dim // _lib.gen_nparams(model.hparams.generator_distribution.name)
         self.Zd = model.latent_dim
         self.P = model.generator_network.output_dim
         f = dict(device=device, dtype=torch.float32)
@@ -82,6 +82,7 @@ def _lair_bufs(ws, X, M8, cfg, draws, return_resampled_latents, clip_min, clip_m
     dev = X.device
     g = lambda k, dt: (draws[k].to(dev, dt).contiguous() if draws.get(k) is not None else None)
     keep = [g("eps_z", torch.float32), g("eps_x", torch.float32)]
+    chi2 = g("chi2_x", torch.float32)  # Student-t generators: chi-square draws beside the normals of eps_x
     systematic = cfg.method == _lib.CS_METHOD["systematic"]
     if systematic:
         keep += [g("u_res", torch.float32), g("u_res2", torch.float32)]
@@ -100,8 +101,8 @@ def _lair_bufs(ws, X, M8, cfg, draws, return_resampled_latents, clip_min, clip_m
                           perplexity=ws.stats[2],
                           latents_resampled=ws.latents_resampled if return_resampled_latents else None,
                           idx2=ws.idx2 if return_resampled_latents else None,
-                          clip_min=clip_min, clip_max=clip_max, X_out=X_out, **ud)
-    return bufs, keep
+                          clip_min=clip_min, clip_max=clip_max, X_out=X_out, chi2_x=chi2, **ud)
+    return bufs, keep + [chi2]
 
 
 def lair_step(model, ws, X, M8, cfg, *, rng=None, draws=None, return_resampled_latents=False,
@@ -150,17 +151,19 @@ def decode_params(model, Z):
 
 
 def sample_impute(model, gen, X, M8, K, *, eps=None, rng=None, stream_id=_lib.STREAM_X, clip_min=None,
-                  clip_max=None, zero_missing=False, nonfinite_keep=False):
-    """X[B,K,D] <- X*M + sample(gen)*(1-M) in place (M8 None: X <- sample)."""
+                  clip_max=None, zero_missing=False, nonfinite_keep=False, chi2=None):
+    """X[B,K,D] <- X*M + sample(gen)*(1-M) in place (M8 None: X <- sample).  ``chi2``: the injected chi-square draws
+    of a Student-t generator (beside the standard normals in ``eps``)."""
     _, gd = model.engine_dists()
     D = X.shape[-1]
     B = X.numel() // (K * D)
     eps = eps.to(X.device, torch.float32).contiguous() if eps is not None else None
+    chi2 = chi2.to(X.device, torch.float32).contiguous() if chi2 is not None else None
     rng = rng if rng is not None else _lib.make_rng(0)
-    _lib.check(_lib.lib().cs_sample_impute(_lib.ptr(gen), gd, _lib.ptr(eps), C.byref(rng), stream_id, _lib.ptr(X),
-                                           _lib.ptr(M8), B, K, D, _lib.ptr(clip_min), _lib.ptr(clip_max),
-                                           int(zero_missing) | (2 if nonfinite_keep else 0),
-                                           _lib.current_stream()))
+    _lib.check(_lib.lib().cs_sample_impute2(_lib.ptr(gen), gd, _lib.ptr(eps), _lib.ptr(chi2), C.byref(rng), stream_id,
+                                            _lib.ptr(X), _lib.ptr(M8), B, K, D, _lib.ptr(clip_min), _lib.ptr(clip_max),
+                                            int(zero_missing) | (2 if nonfinite_keep else 0),
+                                            _lib.current_stream()))
     return X
 
 
@@ -199,7 +202,7 @@ def vae_sample(model, num_samples, *, rng=None, draws=None, return_latents=False
     if uniform:
         Z = Z * (1. + 1e-8)
     gen = decode_params(model, Z)
-    D = gen.shape[-1] // (1 if model.hparams.generator_distribution.name == "bern" else 2)
+    D = gen.shape[-1] // _lib.gen_nparams(model.hparams.generator_distribution.name)
     X = torch.empty(num_samples, D, device=dev, dtype=torch.float32)
     sample_impute(model, gen, X, None, 1, eps=draws.get("eps_x"), rng=rng, stream_id=_lib.STREAM_INIT_X)
     return (X, Z) if return_latents else X

@@ -608,6 +608,185 @@ __global__ void __launch_bounds__(64 * NW) cs_conv3x3_halo_split_kernel(const Cs
     for (int p = 0; p < PT; ++p) conv_store<CT>(a, acc[p], p0 + row0[p], blockIdx.y * (CT * 32), h);
   }
 }
+// 32 -> 32 channel same-size 3x3 convolutions (the 14x14 stages of the MNIST-GMM nets): 30 algorithmic GFLOP against
+// 0.4-0.6 GB of activations per layer at 8192 images, bound by HBM, and a block of the kernel above is all prologue and
+// epilogue (one 32-channel chunk).  Here the whole split weight set (9 taps x 6 KiB) stays in LDS and a persistent
+// workgroup per CU walks over items of 32*NW pixels: the next item's window is requested before the current item's
+// matrix instructions and staged behind them, the residual rows are requested before them too, the stores are never
+// waited for; two barriers per item, none inside it.
+template <int NW>
+__global__ void __launch_bounds__(64 * NW) cs_conv3x3_halo_resident_kernel(const CsConvArgs a, int NR, int NP, int nitems) {
+  constexpr int NTHR = 64 * NW, RPP = NTHR / 8;
+  constexpr int ROWB = 192, W_B = 6144, NPMAX = 6;
+  constexpr int RS = 128 + 16;  // transposition row: 32 channels + padding
+  extern __shared__ __attribute__((aligned(1024))) unsigned char s_raw[];
+  lds_byte* s_w = (lds_byte*)s_raw;                     // [9][W_B]
+  lds_byte* s_halo = s_w + 9 * W_B;                     // [NR][ROWB], then 256 bytes of zeros
+  lds_byte* s_t = s_halo + (((unsigned)NR * ROWB + 256u + 1023u) & ~1023u);  // [NW][32][RS]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = (int)cs_scalar_u32((unsigned)tid >> 6);
+  const int h = lane >> 5, l31 = lane & 31, c4 = tid & 7;
+  const int W = a.win, H = a.hin;
+  const unsigned zero_off = (unsigned)NR * ROWB;
+  if (NW == 8 && wave >= 4) __builtin_amdgcn_s_setprio(1);
+
+  f32x4 rh[NPMAX];
+  auto fetch_halo = [&](int item) {
+    const int64_t q0 = (int64_t)item * (32 * NW) - (W + 1);
+#pragma unroll
+    for (int p = 0; p < NPMAX; ++p) {
+      const int row = (tid >> 3) + RPP * p;
+      const int64_t q = q0 + row;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (p < NP && row < NR && q >= 0 && q < a.npix) v = *(const f32x4*)(a.in + q * 32 + c4 * 4);
+      rh[p] = v;
+    }
+  };
+  auto stash_halo = [&]() {
+#pragma unroll
+    for (int p = 0; p < NPMAX; ++p) {
+      const int row = (tid >> 3) + RPP * p;
+      if (p < NP && row < NR) {
+        const f32x4 v = rh[p];
+        const unsigned a0 = conv_cvt_pk(v.x, v.y), b0 = conv_cvt_pk(v.z, v.w);
+        const float r0 = v.x - __uint_as_float(a0 << 16), r1 = v.y - __uint_as_float(a0 & 0xffff0000u);
+        const float r2 = v.z - __uint_as_float(b0 << 16), r3 = v.w - __uint_as_float(b0 & 0xffff0000u);
+        const unsigned a1 = conv_cvt_pk(r0, r1), b1 = conv_cvt_pk(r2, r3);
+        const unsigned a2 = conv_cvt_pk(r0 - __uint_as_float(a1 << 16), r1 - __uint_as_float(a1 & 0xffff0000u));
+        const unsigned b2 = conv_cvt_pk(r2 - __uint_as_float(b1 << 16), r3 - __uint_as_float(b1 & 0xffff0000u));
+        lds_byte* dst = s_halo + row * ROWB + (((c4 >> 1) ^ ((row >> 2) & 3)) << 4) + ((c4 & 1) << 3);
+        *(__attribute__((address_space(3))) u32x2n*)(dst) = u32x2n{a0, b0};
+        *(__attribute__((address_space(3))) u32x2n*)(dst + 64) = u32x2n{a1, b1};
+        *(__attribute__((address_space(3))) u32x2n*)(dst + 128) = u32x2n{a2, b2};
+      }
+    }
+  };
+
+  // all weight tiles: tile of tap t = [t][cin/32 = 1][cout_p/32 = 1] brick; 54 copies of 1 KiB over the waves
+  {
+    const unsigned ring_lds = cs_scalar_u32((unsigned)(size_t)s_w);
+    for (int piece = wave; piece < 54; piece += NW) {
+      const unsigned long long src = (unsigned long long)((const unsigned char*)a.w3 + (int64_t)piece * 1024);
+      const void* ssrc =
+          (const void*)(((unsigned long long)cs_scalar_u32((unsigned)(src >> 32)) << 32) | cs_scalar_u32((unsigned)src));
+      cs_dma16(ssrc, (unsigned)lane * 16u, ring_lds + (unsigned)piece * 1024u);
+    }
+  }
+  if (tid < 16) *(lds_u32x4n*)(s_halo + zero_off + tid * 16) = u32x4n{0u, 0u, 0u, 0u};
+  if ((int)blockIdx.x < nitems) fetch_halo(blockIdx.x);
+  stash_halo();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  const lds_byte* wl = s_w + lane * 16;
+  // lane's part of the transposed tile: row lr (of 8 per pass), channels lc .. lc + 3
+  const int lr = lane >> 3, lc = (lane & 7) * 4;
+  lds_byte* tw = s_t + wave * (32 * RS);
+  f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+  if (a.bias) bias4 = *(const f32x4*)(a.bias + lc);
+
+  for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+    const int64_t p0 = (int64_t)item * (32 * NW);
+    const int row0 = wave * 32 + l31;
+    const int64_t gp = p0 + row0;
+    unsigned tapmask = 0;
+    {
+      const int hw = H * W;
+      const unsigned g = gp < a.npix ? (unsigned)gp : 0u;
+      const int rem = (int)(g % (unsigned)hw);
+      const int oh = rem / W, ow = rem - oh * W;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int ih = oh + t / 3 - 1, iw = ow + t % 3 - 1;
+        if (gp < a.npix && ih >= 0 && ih < H && iw >= 0 && iw < W) tapmask |= 1u << t;
+      }
+    }
+    auto b_addr = [&](int tap) -> unsigned {
+      const int rowB = row0 + (tap / 3) * W + (tap % 3);
+      const unsigned o = (unsigned)rowB * ROWB + (unsigned)((h ^ ((rowB >> 2) & 3)) << 4);
+      return ((tapmask >> tap) & 1u) ? o : zero_off + (unsigned)(h << 4);
+    };
+    // requests that the matrix instructions below cover: the next item's window, this item's residual rows
+    const int next = item + gridDim.x;
+    if (next < nitems) fetch_halo(next);
+    f32x4 rs[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int64_t g2 = p0 + wave * 32 + i * 8 + lr;
+      rs[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (a.res && g2 < a.npix) rs[i] = *(const f32x4*)(a.res + g2 * a.cout + lc);
+    }
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    u32x4n wr[2][3], br[2][3];
+    unsigned bo = b_addr(0), bn = 0;
+#pragma unroll
+    for (int tm = 0; tm < 3; ++tm) {
+      wr[0][tm] = *(const lds_u32x4n*)(wl + tm * 1024);
+      br[0][tm] = *(const lds_u32x4n*)(s_halo + bo + tm * 64);
+    }
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      if (tap < 8) bn = b_addr(tap + 1);
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        // fragments of the next group (the first group of the next tap behind the second one)
+        if (s == 0) {
+#pragma unroll
+          for (int tm = 0; tm < 3; ++tm) {
+            wr[1][tm] = *(const lds_u32x4n*)(wl + tap * W_B + (3 + tm) * 1024);
+            br[1][tm] = *(const lds_u32x4n*)(s_halo + (bo ^ 32u) + tm * 64);
+          }
+        } else if (tap < 8) {
+#pragma unroll
+          for (int tm = 0; tm < 3; ++tm) {
+            wr[0][tm] = *(const lds_u32x4n*)(wl + (tap + 1) * W_B + tm * 1024);
+            br[0][tm] = *(const lds_u32x4n*)(s_halo + bn + tm * 64);
+          }
+        }
+        const u32x4n(&w)[3] = wr[s];
+        const u32x4n(&b)[3] = br[s];
+        CS_CONV_MFMA32(w[0], b[0], acc);
+        CS_CONV_MFMA32(w[0], b[1], acc);
+        __builtin_amdgcn_sched_barrier(0);
+        CS_CONV_MFMA32(w[1], b[0], acc);
+        CS_CONV_MFMA32(w[0], b[2], acc);
+        __builtin_amdgcn_sched_barrier(0);
+        CS_CONV_MFMA32(w[1], b[1], acc);
+        CS_CONV_MFMA32(w[2], b[0], acc);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      bo = bn;
+    }
+    cs_mfma_drain();
+    // epilogue: transpose through the wave's LDS region so that a store covers 8 whole pixel rows
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      *(conv_lds_f32x4*)(tw + l31 * RS + (8 * q + 4 * h) * 4) = f32x4{acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = i * 8 + lr;
+      const int64_t g2 = p0 + wave * 32 + row;
+      f32x4 o = *(const conv_lds_f32x4*)(tw + row * RS + lc * 4) + bias4 + rs[i];
+      if (a.relu) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = fmaxf(o[r], 0.0f);
+      }
+      if (g2 < a.npix) *(f32x4*)(a.out + g2 * a.cout + lc) = o;
+    }
+    if (next < nitems) {
+      // barriers without a wait for the stores above (only LDS traffic has to be settled)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();  // every read of this item's window is done
+      stash_halo();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+  }
+}
+
 #undef CS_CONV_MFMA32
 
 // Split-bf16 variant of cs_conv_mfma_kernel (any kernel size / stride / upsampling, linear layers):
@@ -1177,7 +1356,25 @@ int launch_conv_mfma(const CsConvArgs& a, hipStream_t stream) {
     }                                                                                                                   \
     hipLaunchKernelGGL(KERNEL_, dim3(gx, a.cout_p / (32 * CT_)), dim3(256), LDS_, stream, a, ##__VA_ARGS__);            \
   } while (0)
-    if (same3) {
+    if (same3 && a.cin == 32 && a.cout == 32 && !a.out_nchw && a.npix < ((int64_t)1 << 31)) {
+      // weights resident in LDS, persistent workgroups (cs_conv3x3_halo_resident_kernel)
+      constexpr int NW_ = 8;
+      const int NR = 32 * NW_ + 2 * (a.win + 1), NP = (NR * 8 + 64 * NW_ - 1) / (64 * NW_);
+      const size_t lds = (size_t)9 * 6144 + (((size_t)NR * 192 + 256 + 1023) & ~(size_t)1023) + (size_t)NW_ * 32 * 144;
+      CS_REQUIRE(NP <= 6 && lds <= 160 * 1024, "halo window does not fit");
+      static bool attr_set[64] = {};
+      static int ncu[64] = {};
+      if (!attr_set[dev]) {
+        CS_HIP(hipFuncSetAttribute((const void*)cs_conv3x3_halo_resident_kernel<NW_>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        CS_HIP(hipDeviceGetAttribute(&ncu[dev], hipDeviceAttributeMultiprocessorCount, dev));
+        attr_set[dev] = true;
+      }
+      const int nitems = (int)((a.npix + 32 * NW_ - 1) / (32 * NW_));
+      const int grid = nitems < ncu[dev] ? nitems : ncu[dev];
+      hipLaunchKernelGGL((cs_conv3x3_halo_resident_kernel<NW_>), dim3((unsigned)grid), dim3(64 * NW_), lds, stream, a, NR,
+                         NP, nitems);
+    } else if (same3) {
       // one 8-wave block per CU (two waves per SIMD); 64-channel layers give a wavefront two pixel tiles so
       // that a weight fragment feeds 12 matrix instructions
       if (a.cout_p % 128 == 0) CS_HALO3_LAUNCH(4, 1, 8);

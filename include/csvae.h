@@ -40,7 +40,7 @@ extern "C" {
 #define CS_DIST_BERN 2            /* logits                           */
 #define CS_DIST_BETA 3            /* latent only: (alpha, beta) = softplus(raw halves); vae.py:239-243 */
 /* Generator (likelihood) families of the LAIR path beyond those (vae.py:220-229, 244-247): layer-program decoders
- * only, AC-MWG entry points reject them.
+ * only.
  *   Student-t: the decoder outputs (df_raw | loc | scale_raw), D each; `gen` holds [loc | scale | df] with
  *   df = softplus(df_raw), scale = softplus(scale_raw) (+ 0.25 for STUDENTT_EPS22).  A sample is
  *   loc + scale * n * rsqrt(c / df), n standard normal (eps_x), c chi-square(df) (chi2_x) as torch's StudentT.rsample.
@@ -299,7 +299,7 @@ typedef struct {
   const uint8_t* M; /* [B,D] */
   /* chain state, updated in place */
   float* Z_old;          /* [B,K,Zd] */
-  float* gen_old;        /* [B,K,2,D] generator mean|scale (Bernoulli: [B,K,D] logits) of Z_old */
+  float* gen_old;        /* [B,K,2,D] generator mean|scale (Bernoulli: [B,K,D] logits; Student-t: [B,K,3,D] loc|scale|df) of Z_old */
   float* z_old_prior_lp; /* [B,K] log p(Z_old) */
   float* x_old_lp;       /* [B,K] masked log-likelihood of X under gen_old */
   /* history */
@@ -323,6 +323,7 @@ typedef struct {
   float* ll_new;      /* [B,K] */
   uint8_t* accepted;  /* [B,K] */
   float* log_accept;  /* [B,K] */
+  const float* chi2_x; /* Student-t generators: injected chi-square(df) draws [B,K,D] beside eps_x (NULL -> counter RNG) */
 } cs_acmwg_bufs;
 
 /* chain state after the warm-up (test_step_vae_sampling.py:1639-1660): q = enc(X),

@@ -195,13 +195,19 @@ def seeded_weights(prefix, in_dim, out_dim, nb, H, seed):
 
 @selectable
 def case_acmwg(ns, name, *, B, K, D, Zd, H, seed, warmup, W, T, p, nkpc=None, cluster=None, R=0, plain_mwg=False,
-               ablation=False, clip=False, temperature=None, anneal=None, nb_enc=1, nb_dec=1, store_weights=True):
+               ablation=False, clip=False, temperature=None, anneal=None, nb_enc=1, nb_dec=1, store_weights=True,
+               gen_dist="normal_with_eps"):
     """AC-MWG sampler class (or, with plain_mwg, TestVAEMetropolisWithinGibbs) against the oracle."""
     from oracle import cs_oracle_samplers as S
+    studentt = gen_dist in ("studentt", "studentt_with_eps22")
     enc = O.make_resfc_weights(D, 2 * Zd, nb_enc, H, seed)
-    dec = O.make_resfc_weights(Zd, 2 * D, nb_dec, H, seed + 1)
-    vae = ref_vae(ns, enc, dec)
+    dec = O.make_resfc_weights(Zd, (3 if studentt else 2) * D, nb_dec, H, seed + 1)
+    if studentt:
+        dec["bf"][:D] += 5.0  # degrees of freedom around 5 (see case_lair)
+    vae = ref_vae(ns, enc, dec, gen_dist=gen_dist)
     X, M = make_inputs(B, K, D, seed + 2)
+    if gen_dist == "logitnormal_with_eps":
+        X = torch.sigmoid(X)
     kw = dict(num_pseudo_warmup_iterations=W, num_mwg_iterations=T,
               warmup_method=warmup, num_copies=K, clip_imputations_during_pg_warmup=clip,
               var_proposal_temperature=temperature, var_proposal_anneal_type_to_prior=anneal, **BASE_KW)
@@ -225,7 +231,7 @@ def case_acmwg(ns, name, *, B, K, D, Zd, H, seed, warmup, W, T, p, nkpc=None, cl
                warmup_method=warmup, num_k_per_cluster=nkpc, glr_cluster_size=cluster,
                num_prior_replenish_proposals=R, plain_mwg=plain_mwg, ablation_use_mwg_target=ablation,
                clip_imputations_during_pg_warmup=clip, var_proposal_temperature=temperature,
-               var_proposal_anneal_type_to_prior=anneal)
+               var_proposal_anneal_type_to_prior=anneal, gen_dist=gen_dist)
     ora = list(S.acmwg_sampler(enc, dec, X.clone(), M, src, **okw))
     assert src.pos == len(entries), "oracle did not consume the whole tape"
     assert len(ora) == len(ref_out)
@@ -249,6 +255,7 @@ def case_acmwg(ns, name, *, B, K, D, Zd, H, seed, warmup, W, T, p, nkpc=None, cl
               cfg=np.array([B, K, D, Zd, H, W, T, nkpc or 0, cluster or 0, R], dtype=np.int64),
               warmup=np.array(warmup), p=np.float64(p), plain_mwg=np.array(plain_mwg), ablation=np.array(ablation),
               clip=np.array(clip), temperature=np.float64(temperature or 0.0), anneal=np.array(anneal or ""),
+              gen_dist=np.array(gen_dist),
               X_seq=np.stack([r["X"].numpy() for r in ref_out]),
               Z_last=ref_out[-1]["Z"].numpy(),
               acceptance=np.array([float(r["acceptance"]) for r in ref_out], dtype=np.float32),
@@ -477,6 +484,10 @@ def main():
               scheme="glr", weighting="dmis_within_groups", cluster=5)
     case_lair(ns, "lair_miniboone_shape", B=3, K=4, R=1, I=1, D=43, Zd=32, H=256, nb_enc=5, nb_dec=2, seed=606,
               iters=1)
+    case_acmwg(ns, "acmwg_gen_studentt", B=3, K=4, D=9, Zd=4, H=64, seed=821, warmup="irwg", W=2, T=8, p=0.2,
+               nkpc=3, cluster=4, R=4, gen_dist="studentt")
+    case_acmwg(ns, "acmwg_gen_logitnormal", B=3, K=4, D=8, Zd=4, H=64, seed=822, warmup="pseudo_gibbs", W=3, T=8, p=0.1,
+               gen_dist="logitnormal_with_eps")
     # likelihood families no configuration uses (irwg/models/vae.py:220-229, 244-247)
     case_lair(ns, "lair_gen_studentt", B=5, K=4, R=1, I=1, D=11, Zd=5, H=64, nb_enc=1, nb_dec=1, seed=811,
               gen_dist="studentt")

@@ -703,7 +703,7 @@ def pseudo_gibbs_iteration(enc, dec, X, M, draws, *, latent_dist="normal_with_ep
     q_loc, q_scale = split_loc_scale(encoder(X), latent_dist)
     Z = q_loc + q_scale * draws["eps_z"]
     params = decoder(Z)
-    X_m = gen_sample(params, gen_dist, draws["eps_x"])
+    X_m = gen_sample(params, gen_dist, draws["eps_x"], draws.get("chi2_x"))
     if clip_min is not None:
         X_m = torch.max(X_m, clip_min)
     if clip_max is not None:
@@ -720,7 +720,7 @@ def vae_samples_imputation(dec, X, M, draws, *, gen_dist="normal_with_eps", deco
     decoder = decoder or (lambda z: resfc_forward(dec, z))
     B, K, D = X.shape
     z = draws["z"] * (1. + 1e-8) if prior == "uniform" else draws["z"]  # 'z' = torch.rand under the uniform prior
-    X_imp = gen_sample(decoder(z), gen_dist, draws["eps_x"]).reshape(B, K, D)
+    X_imp = gen_sample(decoder(z), gen_dist, draws["eps_x"], draws.get("chi2_x")).reshape(B, K, D)
     Xc = X.clone()
     Xc[(~M).expand(B, K, D)] = 0.0
     return Xc * M + X_imp * (~M)
@@ -924,7 +924,7 @@ def acmwg_step(enc, dec, state, M, hist_X, draws, *, prior_mixture_probability,
     Z_upd = Z_old * na.unsqueeze(-1) + Z_new * accepted.unsqueeze(-1)
     zp_upd = state["Z_old_prior_logprob"] * na + zn_prior * accepted
     mp_upd = state["mis_params_old"] * na.unsqueeze(-1) + mis_params * accepted.unsqueeze(-1)
-    X_m = gen_sample(mp_upd, gen_dist, draws["eps_x"])
+    X_m = gen_sample(mp_upd, gen_dist, draws["eps_x"], draws.get("chi2_x"))
     X_new = X * M + X_m * (~M)
     x_old_lp = gen_log_prob(X_new, mp_upd, gen_dist)
     x_old_lp = (x_old_lp if joint_target_old else x_old_lp * M).sum(-1)

@@ -20,6 +20,17 @@ import torch
 from . import cs_oracle as O
 
 
+def x_draws(src, gen_dist, *shape):
+    """Draws of one generator sample of the given shape, in the reference's order: uniforms for Bernoulli, standard
+    normals otherwise, and for the Student-t families the chi-square draws behind them (StudentT.rsample)."""
+    if gen_dist == "bern":
+        return {"eps_x": src.uniform(*shape)}
+    d = {"eps_x": src.normal(*shape)}
+    if gen_dist in ("studentt", "studentt_with_eps22"):
+        d["chi2_x"] = src.chi2(*shape)
+    return d
+
+
 class TapeSource:
     """Replays a recorded draw tape [(kind, ndarray), ...] in order."""
 
@@ -44,6 +55,12 @@ class TapeSource:
     def beta(self, *shape):
         """Samples of a Beta posterior as torch's Dirichlet sampler returned them."""
         return self._take(("beta",), shape)
+
+    def chi2(self, *shape):
+        """Chi-square draws of StudentT.rsample: Chi2(df).rsample() = _standard_gamma(df / 2) / 0.5, clamped to tiny
+        (torch.distributions.Gamma.rsample); the tape holds the standard-gamma variates."""
+        g = self._take(("std_gamma",), shape)
+        return (g / 0.5).clamp(min=torch.finfo(torch.float32).tiny)
 
     def uniform64(self, *shape):
         return self._take(("multinomial",), shape)
@@ -137,8 +154,7 @@ class SeededSource:
 def initial_imputation(dec, X, M, src, gen_dist="normal_with_eps", prior="std_normal"):
     B, K, D = X.shape
     Zd = O.net_input_dim(dec)
-    draws = {"z": src.uniform(B * K, Zd) if prior == "uniform" else src.normal(B * K, Zd),
-             "eps_x": src.uniform(B * K, D) if gen_dist == "bern" else src.normal(B * K, D)}
+    draws = {"z": src.uniform(B * K, Zd) if prior == "uniform" else src.normal(B * K, Zd), **x_draws(src, gen_dist, B * K, D)}
     return O.vae_samples_imputation(dec, X, M, draws, gen_dist=gen_dist, prior=prior)
 
 
@@ -162,7 +178,7 @@ def _lair_draws(src, I, B, K, R, D, Zd, *, scheme, method, cluster, gen_dist, se
     d["u_res"] = res()
     if second:
         d["u_res2"] = res()
-    d["eps_x"] = src.uniform(B, K_out, D) if gen_dist == "bern" else src.normal(B, K_out, D)
+    d.update(x_draws(src, gen_dist, B, K_out, D))
     return d
 
 
@@ -184,7 +200,7 @@ def lair_sampler(enc, dec, X, M, src, *, num_iterations, num_imp_samples=1, weig
     H = num_historical_proposals
     history = O.ImputationHistory(imputation_history_length, X.shape, X.dtype) if H is not None else None
     for t in range(num_pseudo_warmup_iterations):
-        draws = {"eps_z": src.normal(B, K, Zd), "eps_x": src.uniform(B, K, D) if gen_dist == "bern" else src.normal(B, K, D)}
+        draws = {"eps_z": src.normal(B, K, Zd), **x_draws(src, gen_dist, B, K, D)}
         X, Zpg = O.pseudo_gibbs_iteration(enc, dec, X, M, draws, latent_dist=latent_dist, gen_dist=gen_dist)
         if history is not None:
             history.enqueue(X)
@@ -258,8 +274,8 @@ def lair_final_resample(dec, Z_props, log_ws, X_true, M, src, *, num_samples=Non
         Zb = Z[:, c0:c0 + Kp]
         params = O.resfc_forward(dec, Zb)
         D = Xz.shape[-1]
-        draw = src.uniform(B, Zb.shape[1], D) if gen_dist == "bern" else src.normal(B, Zb.shape[1], D)
-        X_m = O.gen_sample(params, gen_dist, draw)
+        dx = x_draws(src, gen_dist, B, Zb.shape[1], D)
+        X_m = O.gen_sample(params, gen_dist, dx["eps_x"], dx.get("chi2_x"))
         imps.append(Xz * M + X_m * (~M))
     return idx, Z, torch.cat(imps, dim=1)
 
@@ -309,11 +325,11 @@ def acmwg_sampler(enc, dec, X, M, src, *, num_pseudo_warmup_iterations, num_mwg_
     elif warmup_method == "pseudo_gibbs":
         for t in range(W):
             draws = {"eps_z": src.normal(B, K, Zd),
-                     "eps_x": src.uniform(B, K, D) if gen_dist == "bern" else src.normal(B, K, D)}
+                     **x_draws(src, gen_dist, B, K, D)}
             q_loc, q_scale = O.split_loc_scale(O.resfc_forward(enc, X), latent_dist)
             Z_new = q_loc + q_scale * draws["eps_z"]
             mis_params = O.resfc_forward(dec, Z_new)
-            X_m = O.gen_sample(mis_params, gen_dist, draws["eps_x"])
+            X_m = O.gen_sample(mis_params, gen_dist, draws["eps_x"], draws.get("chi2_x"))
             if clip_imputations_during_pg_warmup:
                 X_m = torch.min(torch.max(X_m, clip_min), clip_max)
                 X_m = torch.where(~X_m.isfinite(), X, X_m)
@@ -360,7 +376,7 @@ def acmwg_sampler(enc, dec, X, M, src, *, num_pseudo_warmup_iterations, num_mwg_
     if plain_mwg:
         for t in range(num_mwg_iterations):
             draws = {"eps_z": src.normal(B, K, Zd), "u_accept": src.uniform(B, K),
-                     "eps_x": src.uniform(B, K, D) if gen_dist == "bern" else src.normal(B, K, D)}
+                     **x_draws(src, gen_dist, B, K, D)}
             o = O.acmwg_step(enc, dec, state, M, state["X"], draws, prior_mixture_probability=0.0,
                              latent_dist=latent_dist, gen_dist=gen_dist, joint_target_new=True, joint_target_old=True,
                              **tkw)
@@ -382,7 +398,7 @@ def acmwg_sampler(enc, dec, X, M, src, *, num_pseudo_warmup_iterations, num_mwg_
             draws["z_prior"] = src.normal(B, K, Zd)
             draws["u_prior"] = src.uniform(B, K)
         draws["u_accept"] = src.uniform(B, K)
-        draws["eps_x"] = src.uniform(B, K, D) if gen_dist == "bern" else src.normal(B, K, D)
+        draws.update(x_draws(src, gen_dist, B, K, D))
         o = O.acmwg_step(enc, dec, state, M, hist_X, draws, prior_mixture_probability=prior_mixture_probability,
                          latent_dist=latent_dist, gen_dist=gen_dist, joint_target_new=ablation_use_mwg_target, **tkw)
         hist.update_available(o["accepted"])
@@ -405,7 +421,7 @@ def pseudo_gibbs_sampler(enc, dec, X, M, src, *, num_iterations, clip_imputation
         clip_min = torch.min(Xt, dim=0)[0] * 2
     for t in range(num_iterations):
         draws = {"eps_z": src.normal(B, K, Zd),
-                 "eps_x": src.uniform(B, K, D) if gen_dist == "bern" else src.normal(B, K, D)}
+                 **x_draws(src, gen_dist, B, K, D)}
         X, Z = O.pseudo_gibbs_iteration(enc, dec, X, M, draws, latent_dist=latent_dist, gen_dist=gen_dist,
                                         clip_min=clip_min, clip_max=clip_max)
         yield {"X": X, "Z": Z}

@@ -83,18 +83,24 @@ def test_lair_sampler_class_runs_with_the_family(gen_dist):
     assert not torch.equal(outs[0], outs[-1])
 
 
-def test_acmwg_rejects_the_families_it_does_not_implement():
+@pytest.mark.parametrize("gen_dist", ["studentt", "logitnormal_with_eps"])
+def test_acmwg_sampler_class_runs_with_the_family_on_the_counter_rng(gen_dist):
     from tests.test_gpu_samplers import BASE_KW
-    from vae_conditional_sampling_amd import _lib
     from vae_conditional_sampling_amd.sampling.test_step_vae_sampling import TestVAEAdaptiveCollapsedMetropolisWithinGibbs
-    model = _model("studentt")
-    s = TestVAEAdaptiveCollapsedMetropolisWithinGibbs(num_pseudo_warmup_iterations=0, num_mwg_iterations=3,
+    model = _model(gen_dist)
+    s = TestVAEAdaptiveCollapsedMetropolisWithinGibbs(num_pseudo_warmup_iterations=0, num_mwg_iterations=6,
                                                       prior_mixture_probability=0.1, warmup_method="none", num_copies=3,
                                                       **BASE_KW)
     s.set_model(model)
     s.on_test_start()
     s.rng_seed = 1
-    X = torch.randn(4, 3, 12).cuda()
-    M = (torch.rand(4, 1, 12) > 0.5).cuda()
-    with pytest.raises((_lib.CsError, NotImplementedError)):
-        list(s.sampler(X, M))
+    g = torch.Generator().manual_seed(2)
+    X = torch.randn(4, 3, 12, generator=g)
+    if gen_dist == "logitnormal_with_eps":
+        X = torch.sigmoid(X)
+    M = torch.rand(4, 1, 12, generator=g) > 0.5
+    outs = [d["X"].clone() for d in s.sampler(X.cuda(), M.cuda())]
+    Mb = M.cuda().expand(4, 3, 12)
+    assert len(outs) == 6 and all(torch.isfinite(o).all() for o in outs)
+    assert all(torch.equal(o[Mb], X.cuda()[Mb]) for o in outs)
+    assert not torch.equal(outs[0], outs[-1])

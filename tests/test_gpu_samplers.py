@@ -30,7 +30,9 @@ def tape_source(fx):
 @pytest.mark.parametrize("name", ["acmwg_miniboone_config", "acmwg_irwg_warmup", "acmwg_pg_warmup", "acmwg_nowarmup_noprior",
                                   "acmwg_ablation_mwg_target", "acmwg_ablation_pg_warmup",
                                   "mwg_pg_warmup_clip", "mwg_nowarmup", "mwg_irwg_warmup",
-                                  "acmwg_tempered_annealed", "mwg_tempered_annealed"])
+                                  "acmwg_tempered_annealed", "mwg_tempered_annealed",
+                                  # Student-t / logit-normal likelihoods (irwg/models/vae.py:220-229, 244-247)
+                                  "acmwg_gen_studentt", "acmwg_gen_logitnormal"])
 def test_acmwg_sampler_matches_reference_golden(name):
     """AC-MWG (incl. its ablation_use_mwg_target) and the plain Metropolis-within-Gibbs class.
     acmwg_miniboone_config is the MiniBooNE configuration itself (D=43, Zd=32, hidden 256, encoder 5 / decoder 2
@@ -39,7 +41,8 @@ def test_acmwg_sampler_matches_reference_golden(name):
     fx = load_golden(name)
     B, K, D, Zd, H, W, T, nkpc, cluster, R = [int(v) for v in fx["cfg"]]
     warmup = str(fx["warmup"])
-    model = make_model(weights_from_fixture(fx, "enc"), weights_from_fixture(fx, "dec"))
+    model = make_model(weights_from_fixture(fx, "enc"), weights_from_fixture(fx, "dec"),
+                       gen_dist=str(fx["gen_dist"]) if "gen_dist" in fx else "normal_with_eps")
     kw = dict(num_pseudo_warmup_iterations=W, num_mwg_iterations=T, warmup_method=warmup, num_copies=K,
               clip_imputations_during_pg_warmup=bool(fx["clip"]),
               var_proposal_temperature=float(fx["temperature"]) or None,

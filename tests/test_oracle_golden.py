@@ -52,7 +52,8 @@ def test_oracle_lair_iteration(name):
 
 
 MWG_CASES = ["acmwg_miniboone_config", "acmwg_tempered_annealed", "mwg_tempered_annealed", "acmwg_irwg_warmup", "acmwg_pg_warmup", "acmwg_nowarmup_noprior", "acmwg_ablation_mwg_target",
-             "acmwg_ablation_pg_warmup", "mwg_pg_warmup_clip", "mwg_nowarmup", "mwg_irwg_warmup"]
+             "acmwg_ablation_pg_warmup", "mwg_pg_warmup_clip", "mwg_nowarmup", "mwg_irwg_warmup",
+             "acmwg_gen_studentt", "acmwg_gen_logitnormal"]
 
 
 @pytest.mark.parametrize("name", MWG_CASES)
@@ -69,7 +70,8 @@ def test_oracle_acmwg_sampler(name):
                                 ablation_use_mwg_target=bool(fx["ablation"]),
                                 clip_imputations_during_pg_warmup=bool(fx["clip"]),
                                 var_proposal_temperature=float(fx["temperature"]) or None,
-                                var_proposal_anneal_type_to_prior=str(fx["anneal"]) or None))
+                                var_proposal_anneal_type_to_prior=str(fx["anneal"]) or None,
+                                gen_dist=str(fx["gen_dist"]) if "gen_dist" in fx else "normal_with_eps"))
     assert src.pos == len(src.entries)
     mwg = [o for o in outs if "accepted" in o]
     assert np.array_equal(np.stack([o["accepted"].numpy() for o in mwg]), fx["accepted"])

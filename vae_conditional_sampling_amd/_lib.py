@@ -100,7 +100,7 @@ class cs_acmwg_cfg(C.Structure):
 
 _ACMWG_BUF_FIELDS = ["X", "M", "Z_old", "gen_old", "z_old_prior_lp", "x_old_lp", "ring", "avail", "r_hist",
                      "eps_z", "z_prior", "u_prior", "u_accept", "eps_x", "slots", "in_off", "use_prior", "z_alt",
-                     "q", "Z_new", "gen_new", "ll_new", "accepted", "log_accept"]
+                     "q", "Z_new", "gen_new", "ll_new", "accepted", "log_accept", "chi2_x"]
 
 
 class cs_acmwg_bufs(C.Structure):

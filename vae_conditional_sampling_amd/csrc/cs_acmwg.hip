@@ -84,7 +84,9 @@ __global__ void __launch_bounds__(256) cs_acmwg_accept_kernel(const CsAcmwgArgs 
   const int64_t grow = a.rng.row_offset * K + tc;
   const double p = a.cfg.prior_mixture_probability;
   const bool bern = a.cfg.gen_dist == CS_DIST_BERN;
-  const int P = bern ? D : 2 * D;
+  const bool other = a.cfg.gen_dist > CS_DIST_BERN;          // Student-t, logit-normal
+  const bool stt = cs_dist_is_studentt(a.cfg.gen_dist);
+  const int P = cs_gen_nparams(a.cfg.gen_dist) * D;
   const bool use_hist = !(a.cfg.flags & CS_MWG_PROPOSE_FROM_CURRENT);
   const bool joint_old = (a.cfg.flags & CS_MWG_JOINT_TARGET_OLD) != 0;
   auto csum = [&](float v) {
@@ -190,12 +192,15 @@ __global__ void __launch_bounds__(256) cs_acmwg_accept_kernel(const CsAcmwgArgs 
     // inputs of the quad first (X and the generator parameters are updated in place)
     const bool full = d0 + 4 <= D;
     f32x4 xo = {0.f, 0.f, 0.f, 0.f}, g0o = xo, g0n = xo, g1o = {1.f, 1.f, 1.f, 1.f}, g1n = g1o, dr = xo;
+    f32x4 g2o = g1o, g2n = g1o, dc = g1o;  // Student-t: degrees of freedom (old, new), chi-square draws
     float m[4];
     if (full) {
       xo = *(const f32x4_u*)(Xr + d0);
       g0o = *(const f32x4_u*)(go + d0); g0n = *(const f32x4_u*)(gn + d0);
       if (!bern) { g1o = *(const f32x4_u*)(go + D + d0); g1n = *(const f32x4_u*)(gn + D + d0); }
+      if (stt) { g2o = *(const f32x4_u*)(go + 2 * D + d0); g2n = *(const f32x4_u*)(gn + 2 * D + d0); }
       if (a.b.eps_x) dr = *(const f32x4_u*)(a.b.eps_x + tc * D + d0);
+      if (stt && a.b.chi2_x) dc = *(const f32x4_u*)(a.b.chi2_x + tc * D + d0);
       uint32_t mb;
       __builtin_memcpy(&mb, Mr + d0, 4);
 #pragma unroll
@@ -209,7 +214,9 @@ __global__ void __launch_bounds__(256) cs_acmwg_accept_kernel(const CsAcmwgArgs 
         if (in) {
           xo[r] = Xr[d]; g0o[r] = go[d]; g0n[r] = gn[d];
           if (!bern) { g1o[r] = go[D + d]; g1n[r] = gn[D + d]; }
+          if (stt) { g2o[r] = go[2 * D + d]; g2n[r] = gn[2 * D + d]; }
           if (a.b.eps_x) dr[r] = a.b.eps_x[tc * D + d];
+          if (stt && a.b.chi2_x) dc[r] = a.b.chi2_x[tc * D + d];
         }
       }
     }
@@ -223,7 +230,7 @@ __global__ void __launch_bounds__(256) cs_acmwg_accept_kernel(const CsAcmwgArgs 
         dr = cs_normal4(x);
       }
     }
-    f32x4 b0 = xo, b1 = xo, xn4 = xo;  // blended generator parameters, new imputation
+    f32x4 b0 = xo, b1 = xo, b2 = xo, xn4 = xo;  // blended generator parameters, new imputation
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int d = d0 + r;
@@ -235,6 +242,18 @@ __global__ void __launch_bounds__(256) cs_acmwg_accept_kernel(const CsAcmwgArgs 
           xn = xo[r] * m[r] + xm * (1.0f - m[r]);
           lpx = cs_bernoulli_logpmf(xn, lg);
           b0[r] = lg;
+        } else if (other) {
+          const float mean = g0o[r] * fn + g0n[r] * fa;
+          const float sc = g1o[r] * fn + g1n[r] * fa;
+          const float df = g2o[r] * fn + g2n[r] * fa;
+          float c = dc[r];
+          if (stt && !a.b.chi2_x) c = cs_chi2_sample(a.rng, CS_STREAM_X, grow, (uint32_t)d, df);
+          const float xm = cs_gen_sample(a.cfg.gen_dist, mean, sc, df, dr[r], c);
+          xn = xo[r] * m[r] + xm * (1.0f - m[r]);
+          lpx = cs_gen_logpdf(a.cfg.gen_dist, xn, mean, sc, df);
+          b0[r] = mean;
+          b1[r] = sc;
+          b2[r] = df;
         } else {
           const float mean = g0o[r] * fn + g0n[r] * fa;
           const float sc = g1o[r] * fn + g1n[r] * fa;
@@ -252,6 +271,7 @@ __global__ void __launch_bounds__(256) cs_acmwg_accept_kernel(const CsAcmwgArgs 
       if (full) {
         *(f32x4_u*)(go + d0) = b0;
         if (!bern) *(f32x4_u*)(go + D + d0) = b1;
+        if (stt) *(f32x4_u*)(go + 2 * D + d0) = b2;
         *(f32x4_u*)(Xr + d0) = xn4;
         if (ring_row) *(f32x4_u*)(ring_row + d0) = xn4;
         if (ring_row8) {
@@ -264,6 +284,7 @@ __global__ void __launch_bounds__(256) cs_acmwg_accept_kernel(const CsAcmwgArgs 
           if (d0 + r < D) {
             go[d0 + r] = b0[r];
             if (!bern) go[D + d0 + r] = b1[r];
+            if (stt) go[2 * D + d0 + r] = b2[r];
             Xr[d0 + r] = xn4[r];
             if (ring_row) ring_row[d0 + r] = xn4[r];
             if (ring_row8) ring_row8[d0 + r] = xn4[r] != 0.0f;
@@ -294,11 +315,14 @@ __global__ void __launch_bounds__(256) cs_gen_loglik_kernel(const float* gen, in
   if (t >= chains) return;
   const int64_t b = t / K;
   const bool bern = gen_dist == CS_DIST_BERN;
-  const float* g = gen + t * (bern ? D : 2 * D);
+  const float* g = gen + t * cs_gen_nparams(gen_dist) * D;
   float ll = 0.f;
   for (int d = lane; d < D; d += 64) {
     const float x = X[t * D + d];
-    const float lp = bern ? cs_bernoulli_logpmf(x, g[d]) : cs_normal_logpdf(x, g[d], g[D + d]);
+    float lp;
+    if (bern) lp = cs_bernoulli_logpmf(x, g[d]);
+    else if (gen_dist > CS_DIST_BERN) lp = cs_gen_logpdf(gen_dist, x, g[d], g[D + d], cs_dist_is_studentt(gen_dist) ? g[2 * D + d] : 0.0f);
+    else lp = cs_normal_logpdf(x, g[d], g[D + d]);
     ll += M ? lp * (float)M[b * D + d] : lp;
   }
   ll = wsum(ll);
@@ -327,7 +351,9 @@ static int check_acmwg(const cs_acmwg_cfg* c, const cs_acmwg_bufs* b) {
   CS_REQUIRE(c->B >= 0 && c->K >= 1 && c->D >= 1 && c->Zd >= 1, "bad sizes");
   CS_REQUIRE(c->latent_dist == CS_DIST_NORMAL || c->latent_dist == CS_DIST_NORMAL_WITH_EPS,
              "latent distribution must be normal / normal_with_eps");
-  CS_REQUIRE(c->gen_dist >= CS_DIST_NORMAL && c->gen_dist <= CS_DIST_BERN, "bad generator distribution");
+  CS_REQUIRE((c->gen_dist >= CS_DIST_NORMAL && c->gen_dist <= CS_DIST_BERN) || cs_dist_is_studentt(c->gen_dist) ||
+                 c->gen_dist == CS_DIST_LOGITNORMAL_WITH_EPS,
+             "bad generator distribution");
   CS_REQUIRE(c->prior_mixture_probability >= 0.0 && c->prior_mixture_probability < 1.0,
              "prior_mixture_probability must be in [0,1)");
   return CS_OK;
@@ -380,10 +406,9 @@ extern "C" int cs_acmwg_step(const cs_mlp_t* enc, const cs_mlp_t* dec, const cs_
     CS_REQUIRE(c->hist_len >= 1 && c->hist_tail >= 0 && c->hist_tail < c->hist_len, "bad history state");
   }
   CS_REQUIRE(!(use_hist || mix) || (b->use_prior && b->z_alt), "null argument (use_prior / z_alt)");
-  const bool bern = c->gen_dist == CS_DIST_BERN;
   CS_REQUIRE(enc->dev.in_dim == c->D && enc->dev.out_dim == 2 * c->Zd && enc->dev.split == 2,
              "encoder shape does not match the configuration");
-  CS_REQUIRE(dec->dev.in_dim == c->Zd && dec->dev.out_dim == (bern ? 1 : 2) * c->D, "decoder shape mismatch");
+  CS_REQUIRE(dec->dev.in_dim == c->Zd && dec->dev.out_dim == cs_gen_nparams(c->gen_dist) * c->D, "decoder shape mismatch");
   if (c->B == 0) return CS_OK;
   hipStream_t st = (hipStream_t)stream;
   CsAcmwgArgs a;
@@ -540,7 +565,9 @@ extern "C" int cs_history_set_available(int64_t* avail, const uint8_t* mask, int
 extern "C" int cs_gen_loglik_rows(const float* gen, int32_t gen_dist, const float* X, const uint8_t* M, int64_t B,
                                   int32_t K, int32_t D, float* out, void* stream) {
   CS_REQUIRE(gen && X && out && B >= 0 && K >= 1 && D >= 1, "bad argument");
-  CS_REQUIRE(gen_dist >= CS_DIST_NORMAL && gen_dist <= CS_DIST_BERN, "bad generator distribution");
+  CS_REQUIRE((gen_dist >= CS_DIST_NORMAL && gen_dist <= CS_DIST_BERN) || cs_dist_is_studentt(gen_dist) ||
+                 gen_dist == CS_DIST_LOGITNORMAL_WITH_EPS,
+             "bad generator distribution");
   const int64_t chains = B * K;
   if (chains == 0) return CS_OK;
   hipLaunchKernelGGL(cs_gen_loglik_kernel, dim3((unsigned)((chains + 3) / 4)), dim3(256), 0, (hipStream_t)stream, gen,

@@ -204,5 +204,6 @@ def vae_sample(model, num_samples, *, rng=None, draws=None, return_latents=False
     gen = decode_params(model, Z)
     D = gen.shape[-1] // _lib.gen_nparams(model.hparams.generator_distribution.name)
     X = torch.empty(num_samples, D, device=dev, dtype=torch.float32)
-    sample_impute(model, gen, X, None, 1, eps=draws.get("eps_x"), rng=rng, stream_id=_lib.STREAM_INIT_X)
+    sample_impute(model, gen, X, None, 1, eps=draws.get("eps_x"), chi2=draws.get("chi2_x"), rng=rng,
+                  stream_id=_lib.STREAM_INIT_X)
     return (X, Z) if return_latents else X

@@ -47,6 +47,18 @@ def _check_if_bool(X):
     return bool(((X == 0).sum() + (X == 1).sum()) == X.numel())
 
 
+def _x_draws(src, model, *shape):
+    """Injected draws of one generator sample, in the reference's order: uniforms for Bernoulli, standard normals
+    otherwise, and for the Student-t families the chi-square draws behind them (StudentT.rsample)."""
+    name = model.hparams.generator_distribution.name
+    if name == "bern":
+        return {"eps_x": src.uniform(*shape)}
+    d = {"eps_x": src.normal(*shape)}
+    if name in ("studentt", "studentt_with_eps22"):
+        d["chi2_x"] = src.chi2(*shape)
+    return d
+
+
 class TestVAESamplerBase(HyperparametersMixin):
     """Samplers for VAE, base class (harness: chain set-up, initial imputation, loop over the
     sampler generator, storage of the imputation sequence)."""
@@ -260,7 +272,7 @@ class TestVAESamplerBase(HyperparametersMixin):
             bern = self.model.hparams.generator_distribution.name == "bern"
             uni = bool(self.model.hparams.use_uniform_prior)  # VAE.sample draws torch.rand then
             draws = {"z": (src.uniform if uni else src.normal)(B * K, self.model.latent_dim),
-                     "eps_x": src.uniform(B * K, D) if bern else src.normal(B * K, D)}
+                     **_x_draws(src, self.model, B * K, D)}
         # rng rows are (example_offset + b)*K + k of a dedicated stream: independent of batching
         rng = _lib.make_rng(self.rng_seed, 0, self.example_offset * K)
         if draws is not None:
@@ -275,6 +287,7 @@ class TestVAESamplerBase(HyperparametersMixin):
         Xn = X.clone().contiguous()
         rng_x = _lib.make_rng(self.rng_seed, 0, self.example_offset)
         engine.sample_impute(self.model, gen, Xn, engine.mask_u8(M), K, eps=draws["eps_x"] if draws else None,
+                             chi2=draws.get("chi2_x") if draws else None,
                              rng=rng_x, stream_id=_lib.STREAM_INIT_X, zero_missing=True)
         return Xn
 
@@ -379,12 +392,13 @@ def _final_resampling(self, proposals, X_true, M, num_samples):
     gen = engine.decode_params(self.model, Zout.reshape(B * n, Zd))
     D = X_true.shape[-1]
     Xz = X_true.to(dev, torch.float32).unsqueeze(1).repeat(1, n, 1).contiguous()
-    eps = None
+    eps = chi2 = None
     if src is not None:
-        bern = self.model.hparams.generator_distribution.name == "bern"
-        chunks = [(src.uniform if bern else src.normal)(B, min(Kp, n - c0), D) for c0 in range(0, n, Kp)]
-        eps = torch.cat(chunks, dim=1)
-    engine.sample_impute(self.model, gen, Xz, engine.mask_u8(M), n, eps=eps, rng=rng,
+        chunks = [_x_draws(src, self.model, B, min(Kp, n - c0), D) for c0 in range(0, n, Kp)]
+        eps = torch.cat([c["eps_x"] for c in chunks], dim=1)
+        if "chi2_x" in chunks[0]:
+            chi2 = torch.cat([c["chi2_x"] for c in chunks], dim=1)
+    engine.sample_impute(self.model, gen, Xz, engine.mask_u8(M), n, eps=eps, chi2=chi2, rng=rng,
                          stream_id=_lib.STREAM_UFINAL, zero_missing=True)
     return Xz.unsqueeze(0), Zout, idx
 
@@ -486,7 +500,7 @@ class TestVAELatentAdaptiveImportanceResampling(TestVAESamplerBase):
         d["u_res"] = res()
         if second:
             d["u_res2"] = res()
-        d["eps_x"] = src.uniform(B, K_out, D) if bern else src.normal(B, K_out, D)
+        d.update(_x_draws(src, self.model, B, K_out, D))
         return d
 
     def sampler(self, X, M):
@@ -510,7 +524,7 @@ class TestVAELatentAdaptiveImportanceResampling(TestVAESamplerBase):
                 draws = None
                 if self.draw_source is not None:
                     draws = {"eps_z": self.draw_source.normal(B, K, self.model.latent_dim),
-                             "eps_x": self.draw_source.normal(B, K, D)}
+                             **_x_draws(self.draw_source, self.model, B, K, D)}
                 X, Z_imp = pseudo_gibbs_iteration(self.model, X, M, rng=self._rng(), draws=draws, inplace=True)
                 self._next_iteration()
                 if history is not None:
@@ -684,7 +698,7 @@ class TestVAEImportanceResampling(TestVAESamplerBase):
             d["u_res"] = src.uniform(B, K // hp.glr_cluster_size, 1)
         else:
             d["u_res"] = src.uniform(B, K, 1)
-        d["eps_x"] = src.uniform(B, K, D) if bern else src.normal(B, K, D)
+        d.update(_x_draws(src, self.model, B, K, D))
         return d
 
     def sampler(self, X, M):
@@ -754,7 +768,7 @@ class TestVAEPseudoGibbs(TestVAESamplerBase):
             if self.draw_source is not None:
                 src = self.draw_source
                 draws = {"eps_z": src.normal(B, K, self.model.latent_dim),
-                         "eps_x": src.uniform(B, K, D) if bern else src.normal(B, K, D)}
+                         **_x_draws(src, self.model, B, K, D)}
             # the reference calls the same function with and without clip values (:1037-1040); the
             # non-finite safety applies in both cases
             X, Z_imp = pseudo_gibbs_iteration(self.model, X, M, clip_min, clip_max, rng=self._rng(), draws=draws,
@@ -808,7 +822,7 @@ class _MetropolisWithinGibbsCommon(TestVAESamplerBase):
         else:
             d["u_res"] = src.uniform(B, 1) if hp.resampling_scheme == 'gr' else src.uniform(B, G, 1)
         bern = self.model.hparams.generator_distribution.name == "bern"
-        d["eps_x"] = src.uniform(B, Kw, D) if bern else src.normal(B, Kw, D)
+        d.update(_x_draws(src, self.model, B, Kw, D))
         return d
 
     def _pseudo_gibbs_warmup(self, X, M, M8, on_warmup_imputation):
@@ -824,7 +838,7 @@ class _MetropolisWithinGibbsCommon(TestVAESamplerBase):
         for t in range(W):
             draws = None
             if src is not None:
-                draws = {"eps_z": src.normal(B, K, Zd), "eps_x": src.uniform(B, K, D) if bern else src.normal(B, K, D)}
+                draws = {"eps_z": src.normal(B, K, Zd), **_x_draws(src, self.model, B, K, D)}
             if hp.clip_imputations_during_pg_warmup:
                 X, Z_new = pseudo_gibbs_iteration(model, X, M, clip_min, clip_max, rng=self._rng(), draws=draws,
                                                   inplace=True)
@@ -900,7 +914,8 @@ class _MetropolisWithinGibbsCommon(TestVAESamplerBase):
         stq = _lib.current_stream()
         _lib.check(L.cs_lair_encode(model.var_latent_network.packed().handle, C.byref(cfg), C.byref(bufs), stq))
         _lib.check(L.cs_lair_decode(model.generator_network.packed().handle, C.byref(cfg), C.byref(bufs), C.byref(rng), stq))
-        engine.sample_impute(model, ws.gen, X, M8, K, eps=draws["eps_x"] if draws else None, rng=rng,
+        engine.sample_impute(model, ws.gen, X, M8, K, eps=draws["eps_x"] if draws else None,
+                             chi2=draws.get("chi2_x") if draws else None, rng=rng,
                              stream_id=_lib.STREAM_X)
         return X, ws.Z[0]
 
@@ -989,7 +1004,7 @@ class TestVAEMetropolisWithinGibbs(_MetropolisWithinGibbsCommon):
             if src is not None:
                 d["eps_z"] = src.normal(B, K, Zd).to(dev).contiguous()
                 d["u_accept"] = src.uniform(B, K).to(dev).contiguous()
-                d["eps_x"] = (src.uniform(B, K, D) if bern else src.normal(B, K, D)).to(dev).contiguous()
+                d.update({k: v.to(dev).contiguous() for k, v in _x_draws(src, self.model, B, K, D).items()})
             bufs = _lib.make_acmwg_bufs(X=X, M=M8, **st, **wk, **d)
             rng = self._rng()
             _lib.check(L.cs_acmwg_step(h_enc, h_dec, C.byref(cfg), C.byref(bufs), C.byref(rng), stream))
@@ -1116,7 +1131,7 @@ class TestVAEAdaptiveCollapsedMetropolisWithinGibbs(_MetropolisWithinGibbsCommon
                     d["z_prior"] = src.normal(B, K, Zd).to(dev).contiguous()
                     d["u_prior"] = src.uniform(B, K).to(dev).contiguous()
                 d["u_accept"] = src.uniform(B, K).to(dev).contiguous()
-                d["eps_x"] = (src.uniform(B, K, D) if bern else src.normal(B, K, D)).to(dev).contiguous()
+                d.update({k: v.to(dev).contiguous() for k, v in _x_draws(src, self.model, B, K, D).items()})
             bufs = _lib.make_acmwg_bufs(X=X, M=M8, ring=history.history_queue, avail=history.available_timesteps,
                                         **st, **wk, **d)
             rng = self._rng()

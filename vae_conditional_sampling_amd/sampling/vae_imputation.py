@@ -160,6 +160,6 @@ def pseudo_gibbs_iteration(model, X, M, clip_values_min=None, clip_values_max=No
     st = _lib.current_stream()
     _lib.check(L.cs_lair_encode(model.var_latent_network.packed().handle, C.byref(cfg), C.byref(bufs), st))
     _lib.check(L.cs_lair_decode(model.generator_network.packed().handle, C.byref(cfg), C.byref(bufs), C.byref(rng), st))
-    engine.sample_impute(model, ws.gen, X_new, M8, K, eps=draws.get("eps_x"), rng=rng, stream_id=_lib.STREAM_X,
+    engine.sample_impute(model, ws.gen, X_new, M8, K, eps=draws.get("eps_x"), chi2=draws.get("chi2_x"), rng=rng, stream_id=_lib.STREAM_X,
                          clip_min=clip_values_min, clip_max=clip_values_max, nonfinite_keep=True)
     return X_new, ws.Z[0]

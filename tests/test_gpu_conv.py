@@ -204,3 +204,52 @@ def test_repeated_conv_forwards_are_bit_identical():
         e, d = model.var_latent_network(x), model.generator_network(z)
         assert torch.equal(e, ref_e), f"encoder forward {rep} differs in {int((e != ref_e).sum())} entries"
         assert torch.equal(d, ref_d), f"decoder forward {rep} differs in {int((d != ref_d).sum())} entries"
+
+
+def _single_conv_program(cin, cout, hw, *, upsample=1, res=False, seed=0):
+    """One 3x3 convolution (bias, ReLU, optionally a residual input that is the layer's own input) as a layer program."""
+    from vae_conditional_sampling_amd import _lib
+    g = torch.Generator().manual_seed(seed)
+    w = torch.randn(cout, cin, 3, 3, generator=g) / (3 * cin ** 0.5)
+    bias = torch.randn(cout, generator=g) * 0.1
+    out_hw = hw * upsample
+    b = _lib.ProgramBuilder(cin * hw * hw, cout * out_hw * out_hw, 1)
+    b.conv(0, _lib.CS_NET_BUF_OUT, w, bias, hin=hw, win=hw, upsample=upsample, relu=True, res=0 if res else -1)
+    return b.build(), w, bias
+
+
+@pytest.mark.parametrize("case", ["same_size_256ch_7x7", "upsampled_512ch_4x4"])
+def test_launches_divided_over_the_images_match_single_launches(case):
+    """A convolution whose blocks would leave the last round of a 256-CU launch nearly empty runs as two launches
+    (the first images in large blocks, the rest in small ones).  The image counts below trigger that on 256 CUs;
+    every image must come out as when it is computed in a call of a few images (no division), bit for bit, and
+    agree with torch's convolution of the same layer."""
+    if mlp_arith_is_f32():
+        pytest.skip("the exact-f32 kernels launch once")
+    if case == "same_size_256ch_7x7":
+        cin, cout, hw, up, rows = 256, 256, 7, 1, 674   # 130 x 2 blocks of 256 pixels x 128 channels: 1 round + 4
+    else:
+        cin, cout, hw, up, rows = 512, 256, 4, 2, 528   # 33 x 2 x 4 phase blocks: 1 round + 8
+    net, w, bias = _single_conv_program(cin, cout, hw, upsample=up, res=(up == 1), seed=5)
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(rows, cin * hw * hw, generator=g)
+    xd = x.cuda()
+    y = net.forward(xd).clone()
+    for lo, hi in ((0, 6), (rows // 2, rows // 2 + 5), (rows - 9, rows)):
+        part = net.forward(xd[lo:hi].contiguous())
+        assert torch.equal(part, y[lo:hi]), f"images {lo}..{hi} differ from their own launch"
+    # NHWC activations: the program's rows are [pixel][channel]
+    sel = torch.cat([torch.arange(0, 4), torch.arange(rows - 4, rows)])
+    xi = x[sel].reshape(len(sel), hw, hw, cin).permute(0, 3, 1, 2).double()
+    if up == 2:
+        xi = torch.nn.functional.interpolate(xi, scale_factor=2, mode="nearest")
+    ref = torch.nn.functional.conv2d(xi, w.double(), bias.double(), padding=1)
+    if up == 1:
+        ref = ref + x[sel].reshape(len(sel), hw, hw, cin).permute(0, 3, 1, 2).double()
+    ref = torch.relu(ref).permute(0, 2, 3, 1).reshape(len(sel), -1).float()
+    assert_close(y[sel.cuda()], ref, "divided launch against torch", CONV_RTOL)
+
+
+def mlp_arith_is_f32():
+    from vae_conditional_sampling_amd import _lib
+    return _lib.get_mlp_arith() == "f32"

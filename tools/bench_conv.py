@@ -1,6 +1,6 @@
 """Throughput of the ResNet encoder / decoder layer programs at the reference's full sizes.
 
-    python tools/bench_conv.py [omniglot|mnist_gmm] [rows]
+    python tools/bench_conv.py [omniglot|mnist_gmm] [rows] [enc|dec]
 
 FLOPs per image are the algorithmic counts (2*k*k*cin*cout*hout*wout per convolution, 2*in*out per
 linear layer) summed over the program's layers.
@@ -40,7 +40,10 @@ def main():
     dec = ResNetDecoder(**NETS[name]["dec"]).cuda().eval()
     x = torch.randn(rows, enc.input_dim, device="cuda")
     z = torch.randn(rows, dec.input_dim, device="cuda")
+    which = sys.argv[3] if len(sys.argv) > 3 else None
     for label, net, inp in (("enc", enc, x), ("dec", dec, z)):
+        if which is not None and label != which:
+            continue
         fl = program_flops(net)
         # the shader clock needs a few hundred milliseconds of load to settle: warm up for 0.5 s
         t0 = time.perf_counter()

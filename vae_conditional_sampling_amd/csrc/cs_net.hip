@@ -39,6 +39,9 @@ struct CsConvArgs {
   // nearest-neighbour-upsampled convolution): it is pixel (2i + ooh, 2j + oow) of a 2*hout x 2*wout output; with
   // rep it is written to all four pixels (2i + {0,1}, 2j + {0,1}), each with its own residual.
   int osc, ooh, oow, rep;
+  // all four phases of an upsampled convolution in one launch of the halo kernel (grid z = phase 2*ooh + oow):
+  // distance in bf16 entries between the packed weights of consecutive phases
+  int64_t w3_phase_stride;
 };
 
 __device__ __forceinline__ int64_t conv_out_pix(const CsConvArgs& a, int64_t gp, int ooh, int oow) {
@@ -101,12 +104,13 @@ __device__ __forceinline__ void conv_store(const CsConvArgs& a, const f32x16 (&a
 // accumulator tiles (32*PT pixels x 32*CT channels) are transposed through a wave-private LDS region `tw` of
 // 32*PT rows x (128*CT + 16) bytes, so that every store (and residual load) instruction of the wavefront covers
 // 1 KiB of whole pixel rows instead of 32 separate 32-byte pieces.  The caller has made sure that nobody reads the
-// region's previous contents any more.  row_gp = global pixel of the wavefront's first row.
+// region's previous contents any more.  row_gp = global pixel of the wavefront's first row.  PLACED: the rows are
+// phase (ooh, oow) of an upsampled output (conv_out_pix), else output pixel = pixel.
 typedef __attribute__((address_space(3))) unsigned char conv_lds_byte;
 typedef __attribute__((address_space(3))) f32x4 conv_lds_f32x4;
-template <int CT, int PT>
+template <int CT, int PT, bool PLACED>
 __device__ __forceinline__ void conv_store_rows(const CsConvArgs& a, const f32x16 (&acc)[PT][CT], conv_lds_byte* tw,
-                                                int64_t row_gp, int co0, int lane) {
+                                                int64_t row_gp, int co0, int lane, int ooh, int oow) {
   constexpr int RL = CT * 128, RS = RL + 16, LPR = CT * 8, RPI = 64 / LPR;
   const int h = lane >> 5, l31 = lane & 31;
 #pragma unroll
@@ -126,7 +130,7 @@ __device__ __forceinline__ void conv_store_rows(const CsConvArgs& a, const f32x1
     const int row = i * RPI + lr;
     const int64_t gp = row_gp + row;
     v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (a.res && gp < a.npix) v[i] = *(const f32x4*)(a.res + gp * a.cout + co0 + lc);
+    if (a.res && gp < a.npix) v[i] = *(const f32x4*)(a.res + (PLACED ? conv_out_pix(a, gp, ooh, oow) : gp) * a.cout + co0 + lc);
   }
 #pragma unroll
   for (int i = 0; i < 32 * PT / RPI; ++i) {
@@ -137,7 +141,7 @@ __device__ __forceinline__ void conv_store_rows(const CsConvArgs& a, const f32x1
 #pragma unroll
       for (int r = 0; r < 4; ++r) o[r] = fmaxf(o[r], 0.0f);
     }
-    if (gp < a.npix) *(f32x4*)(a.out + gp * a.cout + co0 + lc) = o;
+    if (gp < a.npix) *(f32x4*)(a.out + (PLACED ? conv_out_pix(a, gp, ooh, oow) : gp) * a.cout + co0 + lc) = o;
   }
 }
 
@@ -403,8 +407,14 @@ __device__ __forceinline__ unsigned conv_cvt_pk(float lo, float hi) {
 #define CS_CONV_MFMA32(A_, B_, C_) \
   C_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8n, A_), __builtin_bit_cast(bf16x8n, B_), C_, 0, 0, 0)
 constexpr int CS_HALO_NPMAX = 10;  // staging passes: (32*PT*NW + 2*64) rows * 8 threads / (64*NW) threads
-template <int CT, int PT, int NW>
+template <int CT, int PT, int NW, bool PHASE>
 __global__ void __launch_bounds__(64 * NW) cs_conv3x3_halo_split_kernel(const CsConvArgs a, int NR, int NP) {
+  // PHASE: phase (pa, pb) = (blockIdx.z >> 1, blockIdx.z & 1) of a nearest-neighbour-upsampled 3x3 convolution, a 2x2
+  // convolution of the input at its own resolution (see CsUpsampleMode): tap (dh, dw) reads the input pixel that tap
+  // (pa + dh, pb + dw) of a same-size 3x3 convolution reads, so the window, the tap masks and the fragment addresses
+  // are those of the 3x3 case; the output pixel is (2i + pa, 2j + pb) of the upsampled grid.
+  constexpr int NT = PHASE ? 4 : 9;
+  const int pa = PHASE ? (int)(blockIdx.z >> 1) : 0, pb = PHASE ? (int)(blockIdx.z & 1) : 0;
   constexpr int NTHR = 64 * NW, RPP = NTHR / 8;  // threads; window rows staged per pass
   constexpr int PX = 32 * PT;                    // pixels per wavefront
   constexpr int ROWB = 192, W_B = CT * 6144;
@@ -419,7 +429,8 @@ __global__ void __launch_bounds__(64 * NW) cs_conv3x3_halo_split_kernel(const Cs
   const int W = a.win, H = a.hin;
   const int ncc = a.cin >> 5;
   const int64_t p0 = (int64_t)blockIdx.x * (PX * NW);
-  const unsigned char* wblk = (const unsigned char*)a.w3 + (int64_t)blockIdx.y * W_B;
+  const unsigned char* wblk =
+      (const unsigned char*)(a.w3 + (PHASE ? (int64_t)blockIdx.z * a.w3_phase_stride : 0)) + (int64_t)blockIdx.y * W_B;
   const unsigned zero_off = (unsigned)NR * ROWB;
   if (NW == 8 && wave >= 4) __builtin_amdgcn_s_setprio(1);  // evens out issue arbitration between the two waves of a SIMD
 
@@ -493,9 +504,10 @@ __global__ void __launch_bounds__(64 * NW) cs_conv3x3_halo_split_kernel(const Cs
   };
   // activation fragment address of pixel tile p for tap `tap`, k-step 0 (k-step 1: ^ 32)
   auto b_addr = [&](int tap, int p) -> unsigned {
-    const int rowB = row0[p] + (tap / 3) * W + (tap % 3);
+    const int kh = PHASE ? pa + (tap >> 1) : tap / 3, kw = PHASE ? pb + (tap & 1) : tap % 3;  // position in the 3x3 window
+    const int rowB = row0[p] + kh * W + kw;
     const unsigned o = (unsigned)rowB * ROWB + (unsigned)((h ^ ((rowB >> 2) & 3)) << 4);
-    return ((tapmask[p] >> tap) & 1u) ? o : zero_off + (unsigned)(h << 4);
+    return ((tapmask[p] >> (kh * 3 + kw)) & 1u) ? o : zero_off + (unsigned)(h << 4);
   };
 
   fetch_halo(0);
@@ -511,9 +523,11 @@ __global__ void __launch_bounds__(64 * NW) cs_conv3x3_halo_split_kernel(const Cs
   unsigned bo[PT], bn[PT];
   const lds_byte* wl = s_w + lane * 16;
   for (int cc = 0; cc < ncc; ++cc) {
+    // ring slot of the chunk's first step: 9 taps return to slot 0 with every chunk, 4 taps do not
+    const int sb = PHASE ? (int)cs_scalar_u32((unsigned)(cc % 3)) : 0;
     // first fragments of the chunk: group 0 of tap 0
 #pragma unroll
-    for (int tm = 0; tm < 3; ++tm) wr[0][tm] = *(const lds_u32x4n*)(wl + tm * 1024);
+    for (int tm = 0; tm < 3; ++tm) wr[0][tm] = *(const lds_u32x4n*)(wl + sb * W_B + tm * 1024);
 #pragma unroll
     for (int p = 0; p < PT; ++p) {
       bo[p] = b_addr(0, p);
@@ -521,11 +535,12 @@ __global__ void __launch_bounds__(64 * NW) cs_conv3x3_halo_split_kernel(const Cs
       for (int tm = 0; tm < 3; ++tm) br[0][p][tm] = *(const lds_u32x4n*)(s_halo + bo[p] + tm * 64);
     }
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      const int slot = tap % 3, nslot = (tap + 1) % 3;
-      const bool more = tap < 8 || cc + 1 < ncc;                  // a step follows this one
-      const int tnext = tap < 8 ? (tap + 1) * ncc + cc : cc + 1;  // its weight tile
-      if (tap < 8) {
+    for (int tap = 0; tap < NT; ++tap) {
+      const int slot = PHASE ? (sb + tap >= 3 ? sb + tap - 3 : sb + tap) : tap % 3;
+      const int nslot = PHASE ? (slot == 2 ? 0 : slot + 1) : (tap + 1) % 3;
+      const bool more = tap < NT - 1 || cc + 1 < ncc;                  // a step follows this one
+      const int tnext = tap < NT - 1 ? (tap + 1) * ncc + cc : cc + 1;  // its weight tile
+      if (tap < NT - 1) {
 #pragma unroll
         for (int p = 0; p < PT; ++p) bn[p] = b_addr(tap + 1, p);
       }
@@ -538,7 +553,7 @@ __global__ void __launch_bounds__(64 * NW) cs_conv3x3_halo_split_kernel(const Cs
           __builtin_amdgcn_sched_barrier(0);
           // the next chunk's window: requested behind the barrier of tap 5, so that it has a whole step before
           // the next wait for the DMA copies also waits for it
-          if (tap == 5 && cc + 1 < ncc) fetch_halo(cc + 1);
+          if (tap == (PHASE ? 2 : 5) && cc + 1 < ncc) fetch_halo(cc + 1);
         }
         // fragments of the next group (the first group of the next tap behind the last one)
         if (g + 1 < G) {
@@ -546,7 +561,7 @@ __global__ void __launch_bounds__(64 * NW) cs_conv3x3_halo_split_kernel(const Cs
 #pragma unroll
           for (int tm = 0; tm < 3; ++tm)
             wr[(g + 1) & 1][tm] = *(const lds_u32x4n*)(wl + slot * W_B + ((ct2 * 2 + s2) * 3 + tm) * 1024);
-        } else if (tap < 8) {
+        } else if (tap < NT - 1) {
 #pragma unroll
           for (int tm = 0; tm < 3; ++tm) wr[0][tm] = *(const lds_u32x4n*)(wl + nslot * W_B + tm * 1024);
         }
@@ -556,7 +571,7 @@ __global__ void __launch_bounds__(64 * NW) cs_conv3x3_halo_split_kernel(const Cs
             for (int p = 0; p < PT; ++p)
 #pragma unroll
               for (int tm = 0; tm < 3; ++tm) br[1][p][tm] = *(const lds_u32x4n*)(s_halo + (bo[p] ^ 32u) + tm * 64);
-          } else if (tap < 8) {
+          } else if (tap < NT - 1) {
 #pragma unroll
             for (int p = 0; p < PT; ++p)
 #pragma unroll
@@ -601,8 +616,8 @@ __global__ void __launch_bounds__(64 * NW) cs_conv3x3_halo_split_kernel(const Cs
   cs_mfma_drain();
   if ((a.cout & 31) == 0 && !a.out_nchw) {
     __syncthreads();  // the ring and the window are dead: the LDS becomes per-wave transposition space
-    conv_store_rows<CT, PT>(a, acc, (conv_lds_byte*)s_raw + wave * (PX * (CT * 128 + 16)), p0 + wave * PX,
-                            blockIdx.y * (CT * 32), lane);
+    conv_store_rows<CT, PT, PHASE>(a, acc, (conv_lds_byte*)s_raw + wave * (PX * (CT * 128 + 16)), p0 + wave * PX,
+                                   blockIdx.y * (CT * 32), lane, pa, pb);
   } else {
 #pragma unroll
     for (int p = 0; p < PT; ++p) conv_store<CT>(a, acc[p], p0 + row0[p], blockIdx.y * (CT * 32), h);
@@ -1085,6 +1100,153 @@ __global__ void __launch_bounds__(256) cs_conv_fewout_kernel(const CsConvArgs a)
   }
 }
 
+// 3x3, stride 1, padding 1 convolutions from CIN <= 3 channels to 16 .. 256 NHWC channels (the encoders' first layer):
+// bound by writing the output.  One block per image: the image sits in LDS inside a border of zeros (no bounds
+// checks), cout / 4 lanes share a pixel, each keeps the 9 * CIN * 4 weights of its 4 output channels in registers and
+// stores 16 bytes per pixel (the stores of a wavefront are contiguous).  Plain f32 FMAs in the order of
+// cs_conv_direct_kernel (tap, then input channel): the same results bit for bit.
+template <int CIN>
+__global__ void __launch_bounds__(256) cs_conv3x3_fewin_kernel(const CsConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float s_img[];  // [CIN][H + 2][W + 2]
+  const int H = a.hin, W = a.win, WP = W + 2, plane = (H + 2) * WP, hw = H * W;
+  const int64_t n = blockIdx.x;
+  for (int i = threadIdx.x; i < CIN * plane; i += 256) {
+    const int ci = i / plane, r = i - ci * plane;
+    const int y = r / WP - 1, x = r - (y + 1) * WP - 1;
+    float v = 0.0f;
+    if (y >= 0 && y < H && x >= 0 && x < W)
+      v = a.in_nchw ? a.in[(n * CIN + ci) * hw + y * W + x] : a.in[(n * hw + y * W + x) * CIN + ci];
+    s_img[i] = v;
+  }
+  const int tpp = a.cout >> 2;  // lanes per pixel: a power of two
+  const int co = (threadIdx.x & (tpp - 1)) * 4;
+  float w[9 * CIN][4];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int ci = 0; ci < CIN; ++ci)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) w[t * CIN + ci][v] = a.w[((int64_t)(co + v) * CIN + ci) * 9 + t];
+  f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+  if (a.bias) bias4 = *(const f32x4*)(a.bias + co);
+  __syncthreads();
+  const int ppp = 256 / tpp;  // pixels per pass
+  const float inv_w = 1.0f / (float)W;
+  for (int px = threadIdx.x / tpp; px < hw; px += ppp) {
+    const int oh = (int)(((float)px + 0.5f) * inv_w), ow = px - oh * W;  // exact: (px + 0.5) / W is never within 1/(2W) of an integer
+    const float* ip = s_img + oh * WP + ow;  // top-left corner of the pixel's 3x3 window in the bordered image
+    float sacc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int ci = 0; ci < CIN; ++ci) {
+        const float x = ip[ci * plane + (t / 3) * WP + (t % 3)];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) sacc[v] = fmaf(x, w[t * CIN + ci][v], sacc[v]);
+      }
+    const int64_t gp = n * hw + px;
+    f32x4 o = f32x4{sacc[0], sacc[1], sacc[2], sacc[3]} + bias4;
+    if (a.res) o += *(const f32x4*)(a.res + gp * a.cout + co);
+    if (a.relu) {
+#pragma unroll
+      for (int v = 0; v < 4; ++v) o[v] = fmaxf(o[v], 0.0f);
+    }
+    *(f32x4*)(a.out + gp * a.cout + co) = o;
+  }
+}
+
+// 3x3, stride 1, padding 1 form of cs_conv_fewout_kernel: a block owns `sr` output rows of one image and stages the
+// sr + 2 input rows it reads in LDS inside a border of zeros, so that the input crosses the memory system once
+// (1 + 2 / sr times) instead of once per kernel row.  Same lane layout (cin / 4 lanes per pixel, 4 consecutive input
+// channels each, weights in registers), same order of additions: the same results bit for bit.
+template <int COUT>
+__global__ void __launch_bounds__(256) cs_conv3x3_fewout_strip_kernel(const CsConvArgs a, int sr, int nstrips, int total) {
+  extern __shared__ __attribute__((aligned(16))) float s_strip[];  // [sr + 2][W + 2][cin]
+  typedef __attribute__((address_space(3))) unsigned char strip_lds_byte;
+  const int H = a.hin, W = a.win, WP = W + 2, hw = H * W, cin = a.cin;
+  const int c4n = cin >> 2;  // 16-byte pieces per pixel = lanes per pixel: 8, 16, 32 or 64
+  const int lane = threadIdx.x & 63;
+  const int wave = (int)cs_scalar_u32(threadIdx.x >> 6);
+  const int sub = threadIdx.x & (c4n - 1);
+  const int RB = W * c4n, opr = (RB + 63) >> 6;
+  const unsigned lds0 = cs_scalar_u32((unsigned)(size_t)(strip_lds_byte*)s_strip);
+  float w[9][4][COUT];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int v = 0; v < COUT; ++v) w[t][c][v] = v < a.cout ? a.w[((int64_t)v * cin + sub * 4 + c) * 9 + t] : 0.0f;
+  // the two border pixels of every row stay zero for all strips of the block
+  for (int i = threadIdx.x; i < (sr + 2) * 2 * c4n; i += 256) {
+    const int yy = i / (2 * c4n), r = i - yy * 2 * c4n;
+    const int px = r >= c4n ? W + 1 : 0, c4 = r >= c4n ? r - c4n : r;
+    *(f32x4*)(s_strip + ((yy * WP + px) * c4n + c4) * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const int ppp = 256 / c4n;
+  const float inv_w = 1.0f / (float)W;
+  // the block walks over strips (weights loaded once); several blocks per CU overlap each other's staging
+  for (int strip = blockIdx.x; strip < total; strip += gridDim.x) {
+    const int64_t n = strip / nstrips;
+    const int r0 = (int)(strip - n * nstrips) * sr;  // first output row of the strip
+    const int nr = min(sr, H - r0);
+    // Staging by LDS-DMA (no registers, every copy of the strip in flight at once): an image row is RB consecutive
+    // 16-byte pieces in memory and in LDS; a copy instruction moves up to 64 of them, wavefront `wave` issues copies
+    // wave, wave + 4, ...  Rows above / below the image are written as zeros.
+    for (int op = wave; op < (nr + 2) * opr; op += 4) {
+      const int yy = op / opr, j = op - yy * opr;
+      const int y = r0 - 1 + yy;
+      const int piece = j * 64 + lane;
+      const unsigned dst = (unsigned)((yy * WP + 1) * c4n + j * 64) * 16u;
+      if (piece < RB) {
+        if (y >= 0 && y < H) {
+          const unsigned long long src = (unsigned long long)(a.in + ((n * H + y) * W) * cin + j * 256);
+          const void* ssrc =
+              (const void*)(((unsigned long long)cs_scalar_u32((unsigned)(src >> 32)) << 32) | cs_scalar_u32((unsigned)src));
+          cs_dma16(ssrc, (unsigned)lane * 16u, lds0 + cs_scalar_u32(dst));
+        } else {
+          *(f32x4*)((unsigned char*)s_strip + dst + lane * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int px = threadIdx.x / c4n; px < nr * W; px += ppp) {
+      const int oy = (int)(((float)px + 0.5f) * inv_w), ow = px - oy * W;  // exact: (px + 0.5) / W is never within 1/(2W) of an integer
+      const float* ip = s_strip + ((oy * WP + ow) * cin + sub * 4);
+      float sacc[COUT];
+#pragma unroll
+      for (int v = 0; v < COUT; ++v) sacc[v] = 0.0f;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        // taps outside the image are skipped by cs_conv_fewout_kernel; here they multiply zeros, which leaves the sums as they are
+        const f32x4 x = *(const f32x4*)(ip + ((t / 3) * WP + (t % 3)) * cin);
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+          for (int v = 0; v < COUT; ++v) sacc[v] = fmaf(x[c], w[t][c][v], sacc[v]);
+      }
+#pragma unroll
+      for (int v = 0; v < COUT; ++v)
+        for (int o = c4n >> 1; o > 0; o >>= 1) sacc[v] += __shfl_xor(sacc[v], o);
+      if (sub == 0) {
+        const int rem = (r0 + oy) * W + ow;
+        const int64_t gp = n * hw + rem;
+#pragma unroll
+        for (int v = 0; v < COUT; ++v)
+          if (v < a.cout) {
+            float r = sacc[v];
+            if (a.bias) r += a.bias[v];
+            if (a.res) r += a.res[gp * a.cout + v];
+            if (a.relu) r = fmaxf(r, 0.0f);
+            if (a.out_nchw) a.out[(n * a.cout + v) * hw + rem] = r;
+            else a.out[gp * a.cout + v] = r;
+          }
+      }
+    }
+    __syncthreads();  // the strip is dead: the next one may be copied over it
+  }
+}
 
 // AdaptiveAvgPool2d((1,1)) over NHWC: one thread per (row, channel).
 // nn.LayerNorm(features) over the last dimension (eps 1e-5, biased variance) with its affine
@@ -1299,6 +1461,7 @@ __global__ void __launch_bounds__(64) cs_dec_finish_kernel(const CsMlpArgs a, co
 }
 
 inline unsigned blocks_for(int64_t n) { return (unsigned)((n + 255) / 256); }
+bool g_conv_tail_split = getenv("CSVAE_NO_TAIL_SPLIT") == nullptr;  // measurements without the second launch
 // LDS bytes of cs_conv3x3_halo_split_kernel<CT, PT, NW>: three weight slots, the window, a row of zeros
 // (or, if larger, the epilogue's per-wave transposition regions)
 inline size_t halo3_lds(int ct, int pt, int nw, int win) {
@@ -1326,26 +1489,34 @@ inline void bf16_split3(float v, uint16_t t[3]) {
 int launch_conv_mfma(const CsConvArgs& a, hipStream_t stream) {
   const bool same3 = a.ksize == 3 && a.stride == 1 && a.pad_h == 1 && a.pad_w == 1 && a.us == 0 && a.osc == 1 &&
                      a.hin == a.hout && a.win == a.wout && a.cin % 32 == 0 && a.win + 1 <= 64;
+  // all four phases of an upsampled 3x3 convolution (launch_conv sets w3_phase_stride): the halo kernel's 2x2 form
+  const bool phases4 = a.w3 && a.w3_phase_stride > 0;
   if (a.w3) {
     // split-bf16 arithmetic: the halo kernel for same-size 3x3 convolutions, else the generic one
     const unsigned gx = (unsigned)((a.npix + 127) / 128);
     int dev = 0;
     CS_HIP(hipGetDevice(&dev));
     CS_REQUIRE(dev >= 0 && dev < 64, "device index out of range");
-#define CS_HALO3_LAUNCH(CT_, PT_, NW_)                                                                                   \
+#define CS_HALO3_LAUNCH_(CT_, PT_, NW_, PH_)                                                                             \
   do {                                                                                                                   \
     const int NR = 32 * PT_ * NW_ + 2 * (a.win + 1), NP = (NR * 8 + 64 * NW_ - 1) / (64 * NW_);                          \
     const size_t lds = halo3_lds(CT_, PT_, NW_, a.win);                                                                  \
     CS_REQUIRE(NP <= CS_HALO_NPMAX && lds <= 160 * 1024, "halo window does not fit");                                     \
     static bool attr_set[64] = {};                                                                                       \
     if (!attr_set[dev]) {                                                                                                \
-      CS_HIP(hipFuncSetAttribute((const void*)cs_conv3x3_halo_split_kernel<CT_, PT_, NW_>,                               \
+      CS_HIP(hipFuncSetAttribute((const void*)cs_conv3x3_halo_split_kernel<CT_, PT_, NW_, PH_>,                          \
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                               \
       attr_set[dev] = true;                                                                                              \
     }                                                                                                                    \
-    hipLaunchKernelGGL((cs_conv3x3_halo_split_kernel<CT_, PT_, NW_>),                                                    \
-                       dim3((unsigned)((a.npix + 32 * PT_ * NW_ - 1) / (32 * PT_ * NW_)), a.cout_p / (32 * CT_)),        \
+    hipLaunchKernelGGL((cs_conv3x3_halo_split_kernel<CT_, PT_, NW_, PH_>),                                               \
+                       dim3((unsigned)((a.npix + 32 * PT_ * NW_ - 1) / (32 * PT_ * NW_)), a.cout_p / (32 * CT_),         \
+                            PH_ ? 4 : 1),                                                                                \
                        dim3(64 * NW_), lds, stream, a, NR, NP);                                                          \
+  } while (0)
+#define CS_HALO3_LAUNCH(CT_, PT_, NW_)                  \
+  do {                                                  \
+    if (phases4) CS_HALO3_LAUNCH_(CT_, PT_, NW_, true); \
+    else CS_HALO3_LAUNCH_(CT_, PT_, NW_, false);        \
   } while (0)
 #define CS_CONV3_LAUNCH(KERNEL_, LDS_, ...)                                                                             \
   do {                                                                                                                  \
@@ -1374,13 +1545,48 @@ int launch_conv_mfma(const CsConvArgs& a, hipStream_t stream) {
       const int grid = nitems < ncu[dev] ? nitems : ncu[dev];
       hipLaunchKernelGGL((cs_conv3x3_halo_resident_kernel<NW_>), dim3((unsigned)grid), dim3(64 * NW_), lds, stream, a, NR,
                          NP, nitems);
-    } else if (same3) {
+    } else if (same3 || phases4) {
       // one 8-wave block per CU (two waves per SIMD); 64-channel layers give a wavefront two pixel tiles so
       // that a weight fragment feeds 12 matrix instructions
-      if (a.cout_p % 128 == 0) CS_HALO3_LAUNCH(4, 1, 8);
-      else if (a.cout_p % 64 == 0 && halo3_lds(2, 2, 8, a.win) <= 160 * 1024) CS_HALO3_LAUNCH(2, 2, 8);
-      else if (a.cout_p % 64 == 0) CS_HALO3_LAUNCH(2, 1, 8);
-      else CS_HALO3_LAUNCH(1, 2, 4);
+      const int big = a.cout_p % 128 == 0 ? 0 : a.cout_p % 64 == 0 ? (halo3_lds(2, 2, 8, a.win) <= 160 * 1024 ? 1 : 2) : 3;
+      auto halo = [&](const CsConvArgs& a, bool tail) -> int {  // `a` of the macros: this launch's part of the images
+        if (tail) CS_HALO3_LAUNCH(1, 1, 4);
+        else if (big == 0) CS_HALO3_LAUNCH(4, 1, 8);
+        else if (big == 1) CS_HALO3_LAUNCH(2, 2, 8);
+        else if (big == 2) CS_HALO3_LAUNCH(2, 1, 8);
+        else CS_HALO3_LAUNCH(1, 2, 4);
+        CS_HIP(hipGetLastError());
+        return CS_OK;
+      };
+      // One block occupies a CU, and all blocks of a launch take the same time: B blocks cost ceil(B / CUs) rounds.
+      // Where the last round would be less than an eighth full, the images are divided: the first ones fill whole rounds,
+      // the rest runs as a second launch of small blocks (128 pixels x 32 channels, 4 waves, three to a CU) that
+      // spread over all CUs and whose matrix-instruction chains are an eighth as long.
+      static int ncu[64] = {};
+      if (!ncu[dev]) CS_HIP(hipDeviceGetAttribute(&ncu[dev], hipDeviceAttributeMultiprocessorCount, dev));
+      const int pxb = big == 1 ? 512 : 256, cob = big == 0 ? 128 : big == 3 ? 32 : 64;
+      const int64_t nyz = (int64_t)(a.cout_p / cob) * (phases4 ? 4 : 1);
+      const int64_t nblocks = (a.npix + pxb - 1) / pxb * nyz;
+      const int64_t rounds = nblocks / ncu[dev], last = nblocks - rounds * ncu[dev];
+      const int hw = a.hout * a.wout;
+      const int64_t n1 = rounds * ncu[dev] / nyz * pxb / hw;  // images whose blocks fill `rounds` rounds
+      // (measured: a thinly filled last round costs about half a full one, the second launch 35 us + 60 us per
+      // quarter round of work moved into it: it pays for blocks of at least 54 (tap, 32-channel chunk) steps, 256
+      // channels at 3x3, and thin remainders)
+      if (big != 3 && rounds >= 1 && last > 0 && 8 * last < ncu[dev] && n1 >= 1 && n1 * hw < a.npix &&
+          (a.cin >> 5) * (phases4 ? 4 : 9) >= 54 && g_conv_tail_split) {
+        CsConvArgs a1 = a, a2 = a;
+        a1.npix = n1 * hw;
+        a2.npix = a.npix - n1 * hw;
+        a2.in = a.in + n1 * hw * a.cin;
+        const int64_t opix = n1 * hw * (a.osc == 2 ? 4 : 1) * a.cout;
+        a2.out = a.out + opix;
+        if (a.res) a2.res = a.res + opix;
+        const int rc = halo(a1, false);
+        if (rc != CS_OK) return rc;
+        return halo(a2, true);
+      }
+      return halo(a, false);
     } else if (a.cout_p % 128 == 0) {
       constexpr int CT_ = 4;
       CS_CONV3_LAUNCH((cs_conv_mfma_split_kernel<CT_>), (size_t)(128 + CT_ * 32) * 192);
@@ -1393,6 +1599,7 @@ int launch_conv_mfma(const CsConvArgs& a, hipStream_t stream) {
     }
 #undef CS_CONV3_LAUNCH
 #undef CS_HALO3_LAUNCH
+#undef CS_HALO3_LAUNCH_
     CS_HIP(hipGetLastError());
     return CS_OK;
   }
@@ -1439,7 +1646,27 @@ int launch_conv(const CsProgram& p, const CsLayer& L, const float* in, const flo
   a.npix = rows * d.hout * d.wout;
   a.cout_p = (d.cout + 31) & ~31;
   a.osc = 1; a.ooh = a.oow = 0; a.rep = 0;
+  a.w3_phase_stride = 0;
   a.w3 = nullptr;
+  const bool same3 = d.ksize == 3 && d.stride == 1 && d.pad == 1 && d.upsample == 1 && d.hin == d.hout && d.win == d.wout;
+  if (fewout_eligible(d) && same3 && (size_t)3 * (d.win + 2) * d.cin * 4 <= 48 * 1024) {
+    // strips of `sr` rows whose sr + 2 input rows fit 48 KiB of LDS (three blocks per CU)
+    a.w = p.d_blob + d.w_off;
+    const size_t rowb = (size_t)(d.win + 2) * d.cin * 4;
+    int sr = (int)(48 * 1024 / rowb) - 2;
+    if (sr > d.hin) sr = d.hin;
+    const int nstrips = (d.hin + sr - 1) / sr;
+    sr = (d.hin + nstrips - 1) / nstrips;  // even strips
+    const size_t lds = (size_t)(sr + 2) * rowb;
+    CS_REQUIRE(rows * nstrips < ((int64_t)1 << 31), "too many strips in one launch");
+    const int total = (int)(rows * nstrips);
+    const unsigned gx = (unsigned)(total < 3 * 256 ? total : 3 * 256);
+    if (d.cout == 1) hipLaunchKernelGGL((cs_conv3x3_fewout_strip_kernel<1>), dim3(gx), dim3(256), lds, stream, a, sr, nstrips, total);
+    else if (d.cout == 2) hipLaunchKernelGGL((cs_conv3x3_fewout_strip_kernel<2>), dim3(gx), dim3(256), lds, stream, a, sr, nstrips, total);
+    else hipLaunchKernelGGL((cs_conv3x3_fewout_strip_kernel<4>), dim3(gx), dim3(256), lds, stream, a, sr, nstrips, total);
+    CS_HIP(hipGetLastError());
+    return CS_OK;
+  }
   if (fewout_eligible(d)) {
     a.w = p.d_blob + d.w_off;
     const int ppb = 256 / (d.cin / 4);
@@ -1453,6 +1680,16 @@ int launch_conv(const CsProgram& p, const CsLayer& L, const float* in, const flo
       if (d.cout <= 2) hipLaunchKernelGGL((cs_conv_fewout_kernel<2, 1>), dim3(gx), dim3(256), lds, stream, a);
       else hipLaunchKernelGGL((cs_conv_fewout_kernel<4, 1>), dim3(gx), dim3(256), lds, stream, a);
     }
+    CS_HIP(hipGetLastError());
+    return CS_OK;
+  }
+  if (L.wp_off < 0 && same3 && d.cin <= 3 && !d.out_nchw && d.cout >= 16 && d.cout <= 256 && (d.cout & (d.cout - 1)) == 0 &&
+      (size_t)d.cin * (d.hin + 2) * (d.win + 2) * 4 <= 48 * 1024) {
+    a.w = p.d_blob + d.w_off;
+    const size_t lds = (size_t)d.cin * (d.hin + 2) * (d.win + 2) * 4;
+    if (d.cin == 1) hipLaunchKernelGGL((cs_conv3x3_fewin_kernel<1>), dim3((unsigned)rows), dim3(256), lds, stream, a);
+    else if (d.cin == 2) hipLaunchKernelGGL((cs_conv3x3_fewin_kernel<2>), dim3((unsigned)rows), dim3(256), lds, stream, a);
+    else hipLaunchKernelGGL((cs_conv3x3_fewin_kernel<3>), dim3((unsigned)rows), dim3(256), lds, stream, a);
     CS_HIP(hipGetLastError());
     return CS_OK;
   }
@@ -1484,6 +1721,20 @@ int launch_conv(const CsProgram& p, const CsLayer& L, const float* in, const flo
     return launch_conv_mfma(a, stream);
   }
   a.ksize = 2;
+  {
+    // split arithmetic: one launch of the halo kernel for all four phases where its window fits
+    const int64_t st = L.wph3_off[1] - L.wph3_off[0];
+    const bool spaced = st > 0 && L.wph3_off[2] - L.wph3_off[0] == 2 * st && L.wph3_off[3] - L.wph3_off[0] == 3 * st;
+    // (64 output channels and up: measured on 64 -> 32 channels at 7x7 -> 14x14, 8192 images, the halo kernel's
+    // 256-pixel x 32-channel blocks take 527 us, the four launches of the generic kernel 353)
+    if (split && spaced && d.cin % 32 == 0 && d.cout % 64 == 0 && !d.out_nchw && d.win + 1 <= 64 &&
+        halo3_lds(d.cout % 128 == 0 ? 4 : 2, d.cout % 128 == 0 ? 1 : 2, 8, d.win) <= 160 * 1024) {
+      a.w = p.d_blob + L.wph_off[0];
+      a.w3 = p.d_blob3 + L.wph3_off[0];
+      a.w3_phase_stride = st;
+      return launch_conv_mfma(a, stream);
+    }
+  }
   for (int ph = 0; ph < 4; ++ph) {
     a.ooh = ph >> 1; a.oow = ph & 1;
     a.pad_h = 1 - a.ooh; a.pad_w = 1 - a.oow;

@@ -64,7 +64,7 @@ def resfc_flops(i, H, nb, o):
 
 
 def peak_of(arith):
-    return SPLIT_PEAK_TFLOPS if arith == "bf16x3" else F32_MFMA_PEAK_TFLOPS
+    return {"bf16x3": SPLIT_PEAK_TFLOPS, "bf16": BF16_MFMA_PEAK_TFLOPS}.get(arith, F32_MFMA_PEAK_TFLOPS)
 
 
 def launch_ranks(n):
@@ -210,11 +210,13 @@ class LairCabi:
         res_bytes = (Kp * 2 * Zd * 4 + Kp * Zd * 4 + Kp * 4 + K * (2 * D * 4 + D * 4) + D) + (K * D * 4 + 2 * Kp * 4 + Kp * 8 + 12)
         split = arith == "bf16x3"
         roofline = {"bound": "mfma", "kernel": ((("cs_mlp_split_kernel" if os.environ.get("CSVAE_SPLIT_TILE") == "32" else "cs_mlp_split16_kernel")
-                                                 if split else "cs_mlp_kernel") + " (encoder launch)"),
+                                                 if split else "cs_mlp_split16_kernel<TERMS=1>" if arith == "bf16" else "cs_mlp_kernel")
+                                                + " (encoder launch)"),
                     "achieved": enc_tf, "peak": peak, "unit": "TFLOP/s", "frac": enc_tf / peak,
                     "traffic": None, "flops_per_launch": enc_flops, "avg_launch_ms": enc_ms,
                     "note": ("algorithmic float32 FLOPs; each is executed as 6 bf16 matrix FLOPs, so peak = dense bf16 "
                              "peak 2500 / 6 and the executed bf16 rate is 6 x achieved") if split else
+                            "operands rounded to bf16, one bf16 matrix FLOP per algorithmic FLOP: peak = dense bf16 peak" if arith == "bf16" else
                             "algorithmic float32 FLOPs on the exact-f32 matrix instructions"}
         kernels = {"encoder_ms": enc_ms, "decoder_ms": dec_ms, "resample_impute_ms": res_ms,
                    # HBM-bound stage: algorithmic bytes per example (q, Z, gen_ll, the K chosen generator rows,
@@ -404,6 +406,9 @@ def main():
     if args.arith:
         _lib.set_mlp_arith(args.arith)
     arith = _lib.get_mlp_arith()
+    if arith == "bf16":
+        raise SystemExit("bench.py: the headline is measured in float32-equivalent arithmetic only (bf16x3 or f32); "
+                         "the plain-bf16 mode is reported in the `plain_bf16` block of the same line")
     bench = LairCabi(args.workload, args.batch, rank, dev)
     w, B = bench.w, args.batch
     D, Zd, H, K, R = w["D"], w["Zd"], w["H"], w["K"], w["R"]
@@ -450,6 +455,20 @@ def main():
                  "roofline": {k: r32[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "flops_per_launch", "avg_launch_ms")},
                  "kernels": {k: k32[k] for k in ("encoder_ms", "decoder_ms", "resample_impute_ms", "decoder_frac", "step_mfma_frac")}}
 
+    # and in the opt-in plain-bf16 mode (operands ROUNDED to bf16: reduced precision, never the headline)
+    plain = None
+    if world == 1:
+        _lib.set_mlp_arith("bf16")
+        el, evsb = bench.timed(args.steps, args.warmup)
+        rb, kb = bench.kernel_report(evsb, "bf16")
+        _lib.set_mlp_arith(arith)
+        plain = {"what": "opt-in CS_ARITH_BF16: weights and layer inputs rounded to bf16, one matrix instruction per product, "
+                         "f32 accumulation; REDUCED PRECISION (about 3e-3 of the output scale from the float32 result), checked "
+                         "against a bf16-rounded restatement (tests/test_gpu_bf16_arith.py); not comparable with `value`",
+                 "value": B * K * args.steps / el, "ms_per_step": el / args.steps * 1e3, "unit": "samples/s",
+                 "roofline": {k: rb[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "flops_per_launch", "avg_launch_ms")},
+                 "kernels": {k: kb[k] for k in ("encoder_ms", "decoder_ms", "resample_impute_ms", "decoder_frac", "step_mfma_frac")}}
+
     value = world * B * K * args.steps / elapsed
     split = arith == "bf16x3"
     out = {
@@ -465,6 +484,8 @@ def main():
     }
     if exact is not None:
         out["exact_f32"] = exact
+    if plain is not None:
+        out["plain_bf16"] = plain
     try:
         with open(os.path.join(ROOT, "roofline.json")) as f:
             out["measured_peaks"] = json.load(f)   # what a box of this kind sustains (tools/micro/peaks.hip), for context

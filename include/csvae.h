@@ -428,10 +428,16 @@ int cs_rng_uniform64(const cs_rng* rng, uint32_t stream_id, int64_t rows, int32_
  *                    test_gpu_split_arith.py), they are not bit-identical to it.  Operands that are
  *                    infinite or within a factor 2^-8 of FLT_MAX give NaN where float32 gives +-inf.
  *   CS_ARITH_F32     exact float32 matrix instructions (1.66x the time).
+ *   CS_ARITH_BF16    opt-in throughput mode, never a default: weights and layer inputs rounded to bfloat16
+ *                    (nearest even), one matrix instruction per product, float32 accumulation, biases /
+ *                    ReLU / residual sums / epilogues in float32.  NOT float32-equivalent: every operand carries
+ *                    a relative rounding error of up to 2^-9; results follow a bfloat16-rounded evaluation of
+ *                    the network (tests/test_gpu_bf16_arith.py), not the reference's float32 one.  Fused MLP
+ *                    kernel only; layer-program networks keep CS_ARITH_BF16X3 under this setting.
  * The setting is process-wide and applies to launches made after the call; the environment variable
- * CSVAE_MLP_ARITH (bf16x3 | f32) gives the initial value.  It also selects the kernels of the matrix-core
+ * CSVAE_MLP_ARITH (bf16x3 | f32 | bf16) gives the initial value.  It also selects the kernels of the matrix-core
  * convolution / linear layers of layer-program networks (cs_net_create). */
-enum { CS_ARITH_DEFAULT = -1, CS_ARITH_F32 = 0, CS_ARITH_BF16X3 = 1 };
+enum { CS_ARITH_DEFAULT = -1, CS_ARITH_F32 = 0, CS_ARITH_BF16X3 = 1, CS_ARITH_BF16 = 2 };
 int cs_set_mlp_arith(int arith);
 int cs_get_mlp_arith(void);
 /* The same choice per network handle (fused MLP or layer program): it overrides the process-wide setting for

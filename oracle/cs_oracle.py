@@ -115,6 +115,20 @@ def resfc_forward(w, x):
     return F.linear(h, w["Wf"], w["bf"])
 
 
+def resfc_forward_bf16(w, x):
+    """The residual MLP of `resfc_forward` (no norm layers) in the opt-in plain-bf16 arithmetic of the fused
+    kernel: the weights and the input of every layer rounded to bfloat16 (nearest even), products summed in
+    float32, biases / ReLU / the residual sum in float32.  No counterpart in the reference (float32 throughout):
+    this is the yardstick of tests/test_gpu_bf16_arith.py only."""
+    rb = lambda t: t.to(torch.bfloat16).to(torch.float32)
+    lin = lambda h, W, b: F.linear(rb(h), rb(W)) + b
+    h = F.relu(lin(x, w["W0"], w["b0"]))
+    for W1, b1, W2, b2 in w["blocks"]:
+        t = F.relu(lin(h, W1, b1))
+        h = F.relu((h + b2) + F.linear(rb(t), rb(W2)))
+    return lin(h, w["Wf"], w["bf"])
+
+
 # --------------------------------------------------------------------------------------
 # distributions (vae.py:203-256 + torch.distributions formulas)
 # --------------------------------------------------------------------------------------

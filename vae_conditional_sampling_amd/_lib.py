@@ -171,7 +171,7 @@ def lib():
     return L
 
 
-CS_ARITH = {"f32": 0, "bf16x3": 1}
+CS_ARITH = {"f32": 0, "bf16x3": 1, "bf16": 2}
 
 
 def set_mlp_arith(name):

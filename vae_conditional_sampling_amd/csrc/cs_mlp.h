@@ -24,6 +24,7 @@ struct CsMlpDev {
   // 16-row-tile split-bf16 variant (cs_mlp_split16_kernel.inc): the same three bf16 terms in 16-row tile order;
   // bias table and output tile geometry are those of the exact-f32 kernel (bias, nto, tph)
   const f32x4* wstream16;
+  const f32x4* wstream16b;  // the same order with one term, the weights rounded to bf16 (CS_ARITH_BF16)
   int arith;             // CS_ARITH_* of this network, or -1: the process default (cs_set_mlp_arith)
 };
 
@@ -36,6 +37,7 @@ struct cs_mlp {
   void* d_w3;
   void* d_b3;
   void* d_w16;
+  void* d_w16b;
   int device;
   CsProgram* prog;  // layer-program networks (cs_net_create); null for the fused MLP
 };

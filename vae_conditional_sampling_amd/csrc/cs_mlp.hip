@@ -22,9 +22,9 @@ int cs_mlp_launch_h256(const CsMlpArgs& a, hipStream_t stream);
 int cs_mlp_split_launch_h64(const CsMlpArgs& a, hipStream_t stream);
 int cs_mlp_split_launch_h128(const CsMlpArgs& a, hipStream_t stream);
 int cs_mlp_split_launch_h256(const CsMlpArgs& a, hipStream_t stream);
-int cs_mlp_split16_launch_h64(const CsMlpArgs& a, hipStream_t stream, int waves);
-int cs_mlp_split16_launch_h128(const CsMlpArgs& a, hipStream_t stream, int waves);
-int cs_mlp_split16_launch_h256(const CsMlpArgs& a, hipStream_t stream, int waves);
+int cs_mlp_split16_launch_h64(const CsMlpArgs& a, hipStream_t stream, int waves, int terms);
+int cs_mlp_split16_launch_h128(const CsMlpArgs& a, hipStream_t stream, int waves, int terms);
+int cs_mlp_split16_launch_h256(const CsMlpArgs& a, hipStream_t stream, int waves, int terms);
 
 // Row tile of the split-bf16 arithmetic: 32 (cs_mlp_split_kernel.inc, one wave per SIMD) or 16
 // (cs_mlp_split16_kernel.inc, two waves per SIMD / half the dependent chain per row tile).
@@ -45,25 +45,29 @@ static void cs_split_cfg() {
 
 // Arithmetic of the fused-MLP matrix products: the f32-equivalent 3-way bf16 split (6 bf16 matrix
 // instructions per product, cs_mlp_split_kernel.inc; the default: measured as accurate against a
-// float64 evaluation as the exact-f32 kernel, at 0.6 of its time), or exact f32 matrix instructions.
-// -1 = not decided yet: the environment variable CSVAE_MLP_ARITH (f32 | bf16x3) is read at first use.
+// float64 evaluation as the exact-f32 kernel, at 0.6 of its time), exact f32 matrix instructions, or -- opt-in
+// only, never the default -- plain bf16 (operands rounded to bf16, one matrix instruction per product, f32
+// accumulation: the 16-row kernel with one term per operand; errors of the size of bf16 rounding, 2^-9 relative
+// per operand).
+// -1 = not decided yet: the environment variable CSVAE_MLP_ARITH (f32 | bf16x3 | bf16) is read at first use.
 static int g_arith = -1;
 int cs_mlp_arith() {
   if (g_arith < 0) {
     const char* e = std::getenv("CSVAE_MLP_ARITH");
-    g_arith = (e && std::strcmp(e, "f32") == 0) ? CS_ARITH_F32 : CS_ARITH_BF16X3;
+    g_arith = (e && std::strcmp(e, "f32") == 0) ? CS_ARITH_F32 : (e && std::strcmp(e, "bf16") == 0) ? CS_ARITH_BF16 : CS_ARITH_BF16X3;
   }
   return g_arith;
 }
 extern "C" int cs_set_mlp_arith(int arith) {
-  CS_REQUIRE(arith == CS_ARITH_F32 || arith == CS_ARITH_BF16X3, "unknown arithmetic");
+  CS_REQUIRE(arith == CS_ARITH_F32 || arith == CS_ARITH_BF16X3 || arith == CS_ARITH_BF16, "unknown arithmetic");
   g_arith = arith;
   return CS_OK;
 }
 extern "C" int cs_get_mlp_arith(void) { return cs_mlp_arith(); }
 extern "C" int cs_mlp_set_arith(cs_mlp_t* net, int arith) {
   CS_REQUIRE(net, "null argument");
-  CS_REQUIRE(arith == CS_ARITH_DEFAULT || arith == CS_ARITH_F32 || arith == CS_ARITH_BF16X3, "unknown arithmetic");
+  CS_REQUIRE(arith == CS_ARITH_DEFAULT || arith == CS_ARITH_F32 || arith == CS_ARITH_BF16X3 || arith == CS_ARITH_BF16,
+             "unknown arithmetic");
   net->dev.arith = arith;
   if (net->prog) net->prog->arith = arith;
   return CS_OK;
@@ -83,9 +87,9 @@ extern "C" int cs_debug_set_trace(long long* buf) {
 }
 
 // LDS footprint of the 16-row kernel: bias table + three ring slots (cs_mlp_split16_launch_w)
-static bool cs_split16_fits(const CsMlpDev& n, int waves) {
+static bool cs_split16_fits(const CsMlpDev& n, int waves, int terms) {
   const size_t nthr = 64 * (size_t)waves, mx = (size_t)(n.nt > n.nto ? n.nt : n.nto);
-  const size_t slot_f4 = (mx * 3 * 64 + nthr - 1) / nthr * nthr;
+  const size_t slot_f4 = (mx * terms * 64 + nthr - 1) / nthr * nthr;
   const size_t bias = (((size_t)(2 * n.nb + 2) * n.bias_stride * 4) + 1023) & ~(size_t)1023;
   return bias + 3 * slot_f4 * 16 <= 160 * 1024;
 }
@@ -102,7 +106,9 @@ int cs_mlp_launch(const CsMlpArgs& a_in, hipStream_t stream) {
   cs_split_cfg();
   const int arith = a.net.arith >= 0 ? a.net.arith : cs_mlp_arith();
   const int waves16 = g_split16_waves ? g_split16_waves : (a.rows <= 20480 ? 4 : 8);
-  const bool tile16 = arith == CS_ARITH_BF16X3 && g_split_tile != 32 && cs_split16_fits(a.net, waves16);
+  const bool tile16 = arith == CS_ARITH_BF16 ||
+                      (arith == CS_ARITH_BF16X3 && g_split_tile != 32 && cs_split16_fits(a.net, waves16, 3));
+  if (arith == CS_ARITH_BF16) CS_REQUIRE(cs_split16_fits(a.net, waves16, 1), "network does not fit the LDS budget");
   if (a.mode == CS_MLP_DEC && a.in == nullptr &&
       (a.latent_dist == CS_DIST_BETA || (arith == CS_ARITH_BF16X3 && !tile16))) {
     // Beta proposals are drawn by a kernel of their own; the fused kernel then reads Z as its input.
@@ -119,10 +125,11 @@ int cs_mlp_launch(const CsMlpArgs& a_in, hipStream_t stream) {
     CS_REQUIRE(a.net.split == 2, "generator output must be (loc | scale)");
   if (tile16) {
     switch (a.net.nt) {
-      case 4: return cs_mlp_split16_launch_h64(a, stream, waves16);
-      case 8: return cs_mlp_split16_launch_h128(a, stream, waves16);
-      case 16: return cs_mlp_split16_launch_h256(a, stream, waves16);
+      case 4: return cs_mlp_split16_launch_h64(a, stream, waves16, arith == CS_ARITH_BF16 ? 1 : 3);
+      case 8: return cs_mlp_split16_launch_h128(a, stream, waves16, arith == CS_ARITH_BF16 ? 1 : 3);
+      case 16: return cs_mlp_split16_launch_h256(a, stream, waves16, arith == CS_ARITH_BF16 ? 1 : 3);
     }
+    return cs_fail(CS_EUNSUPPORTED, "no kernel instance for hidden=" + std::to_string(a.net.nt * 16));
   }
   if (arith == CS_ARITH_BF16X3) {
     switch (a.net.nt) {
@@ -201,11 +208,13 @@ void pack_layer3(std::vector<uint16_t>& s, const float* W, int k_real, int kt_co
 // term p of the 3-way split, per lane (m = lane&15, g = lane>>4), the 8 columns
 // k = 32s + 16(j>>2) + 4g + (j&3) of row tile_row(t, m) (-1 = padding): k-slot 8g + j of the matrix instruction
 // carries the feature that a lane of group g holds in register j&3 of tile 2s + (j>>2) of the previous layer.
+// terms = 1: the plain-bf16 stream, one fragment (the rounded weights) per tile.
 template <class RowFn>
-void pack_layer16(std::vector<uint16_t>& s, const float* W, int k_real, int ks_count, int ntiles, RowFn tile_row) {
+void pack_layer16(std::vector<uint16_t>& s, const float* W, int k_real, int ks_count, int ntiles, RowFn tile_row,
+                  int terms = 3) {
   for (int ks = 0; ks < ks_count; ++ks)
     for (int t = 0; t < ntiles; ++t)
-      for (int p = 0; p < 3; ++p)
+      for (int p = 0; p < terms; ++p)
         for (int lane = 0; lane < 64; ++lane) {
           const int m = lane & 15, g = lane >> 4;
           const int n = tile_row(t, m);
@@ -304,10 +313,17 @@ extern "C" int cs_mlp_create(const cs_mlp_desc* d, const float* W0, const float*
     for (int l = 0; l < 2; ++l) pack_layer16(s16, Wblk + ((size_t)b * 2 + l) * H * H, H, NKT, NT, hid_row);
   pack_layer16(s16, Wf, H, NKT, nto, out_row);
   s16.resize(s16.size() + ((size_t)2 * (NT > nto ? NT : nto) * 3 * 64 + 1024) * 8, 0);  // trailing prefetch: a rounded slot
+  std::vector<uint16_t> s16b;  // plain-bf16 arithmetic: one term
+  pack_layer16(s16b, W0, d->in_dim, nkt0, NT, hid_row, 1);
+  for (int b = 0; b < nb; ++b)
+    for (int l = 0; l < 2; ++l) pack_layer16(s16b, Wblk + ((size_t)b * 2 + l) * H * H, H, NKT, NT, hid_row, 1);
+  pack_layer16(s16b, Wf, H, NKT, nto, out_row, 1);
+  s16b.resize(s16b.size() + ((size_t)2 * (NT > nto ? NT : nto) * 64 + 1024) * 8, 0);
 
   cs_mlp* m = new cs_mlp();
   m->desc = *d;
   m->d_w16 = nullptr;
+  m->d_w16b = nullptr;
   m->d_w = nullptr;
   m->d_b = nullptr;
   m->d_w3 = nullptr;
@@ -324,8 +340,11 @@ extern "C" int cs_mlp_create(const cs_mlp_desc* d, const float* W0, const float*
   if (e == hipSuccess) e = hipMemcpy(m->d_b3, bias3.data(), bias3.size() * sizeof(float), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMalloc(&m->d_w16, s16.size() * sizeof(uint16_t));
   if (e == hipSuccess) e = hipMemcpy(m->d_w16, s16.data(), s16.size() * sizeof(uint16_t), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMalloc(&m->d_w16b, s16b.size() * sizeof(uint16_t));
+  if (e == hipSuccess) e = hipMemcpy(m->d_w16b, s16b.data(), s16b.size() * sizeof(uint16_t), hipMemcpyHostToDevice);
   if (e != hipSuccess) {
     if (m->d_w16) (void)hipFree(m->d_w16);
+    if (m->d_w16b) (void)hipFree(m->d_w16b);
     if (m->d_w) (void)hipFree(m->d_w);
     if (m->d_b) (void)hipFree(m->d_b);
     if (m->d_w3) (void)hipFree(m->d_w3);
@@ -351,6 +370,7 @@ extern "C" int cs_mlp_create(const cs_mlp_desc* d, const float* W0, const float*
   m->dev.nto3 = nto3;
   m->dev.bias_stride3 = bst3;
   m->dev.wstream16 = (const f32x4*)m->d_w16;
+  m->dev.wstream16b = (const f32x4*)m->d_w16b;
   m->dev.arith = -1;
   *out = m;
   return CS_OK;
@@ -364,6 +384,7 @@ extern "C" int cs_mlp_destroy(cs_mlp_t* m) {
   if (m->d_w3) (void)hipFree(m->d_w3);
   if (m->d_b3) (void)hipFree(m->d_b3);
   if (m->d_w16) (void)hipFree(m->d_w16);
+  if (m->d_w16b) (void)hipFree(m->d_w16b);
   delete m;
   return CS_OK;
 }

@@ -1703,7 +1703,7 @@ int launch_conv(const CsProgram& p, const CsLayer& L, const float* in, const flo
     CS_HIP(hipGetLastError());
     return CS_OK;
   }
-  const bool split = L.wp3_off >= 0 && (p.arith >= 0 ? p.arith : cs_mlp_arith()) == CS_ARITH_BF16X3;
+  const bool split = L.wp3_off >= 0 && (p.arith >= 0 ? p.arith : cs_mlp_arith()) != CS_ARITH_F32;  // plain bf16 is a fused-MLP arithmetic: layer programs keep the split
   if (L.up_mode == CS_UP_NONE) {
     a.w = p.d_blob + L.wp_off;
     if (split) a.w3 = p.d_blob3 + L.wp3_off;

@@ -363,12 +363,28 @@ def extra_legs(args, arith, dev):
     legs["acmwg_miniboone"] = leg_acmwg_class(model, args.batch, 5, 43, 40, dev, f_enc + f_dec, arith)
     del model
     torch.cuda.empty_cache()
+    def layerwise(model, enc_rows, dec_rows, leg):
+        # The ResNets' layers are not all matrix-bound (32-channel layers on 14x14 images, resizes, the strided 1x1
+        # shortcuts move more bytes than they compute): price every layer at the larger of its matrix time at the
+        # arithmetic's ceiling and its memory time at the HBM peak, and report the iteration against that sum.
+        from vae_conditional_sampling_amd import _lib
+        ideal = (_lib.layerwise_ideal_seconds(model.var_latent_network._program().layers, enc_rows, peak_of(arith) * 1e12) +
+                 _lib.layerwise_ideal_seconds(model.generator_network._program().layers, dec_rows, peak_of(arith) * 1e12))
+        leg["layerwise_roofline"] = {"ideal_ms": ideal * 1e3, "frac": ideal * 1e3 / leg["ms_per_step"],
+                                     "what": "sum over the layers of both networks of max(algorithmic FLOPs / matrix ceiling, "
+                                             "algorithmic activation bytes / 8 TB/s), divided by the measured iteration"}
+        return leg
+
     fe, fd = CONV_FLOPS["omniglot"]
-    legs["acmwg_omniglot_convresnet"] = leg_acmwg_class(conv_vae("omniglot", dev), 400, 5, 784, 12, dev, fe + fd, arith,
-                                                        binary=True, quadrants=True)
+    m = conv_vae("omniglot", dev)
+    legs["acmwg_omniglot_convresnet"] = layerwise(m, 400 * 5, 400 * 5, leg_acmwg_class(m, 400, 5, 784, 12, dev, fe + fd, arith,
+                                                                                      binary=True, quadrants=True))
+    del m
     torch.cuda.empty_cache()
     fe, fd = CONV_FLOPS["mnist_gmm"]
-    legs["lair_mnist_gmm_convresnet"] = leg_lair_class(conv_vae("mnist_gmm", dev), 2048, 4, 1, 196, 12, dev, 4 * fe + 5 * fd, arith)
+    m = conv_vae("mnist_gmm", dev)
+    legs["lair_mnist_gmm_convresnet"] = layerwise(m, 2048 * 4, 2048 * 5, leg_lair_class(m, 2048, 4, 1, 196, 12, dev, 4 * fe + 5 * fd, arith))
+    del m
     torch.cuda.empty_cache()
     return legs
 

@@ -61,8 +61,10 @@ def main():
         from vae_conditional_sampling_amd import _lib
         arith = _lib.get_mlp_arith()
         peak = 157.3 if arith == "f32" else 2500.0 / 6   # algorithmic TFLOP/s: exact f32, or dense bf16 peak / 6 term products
+        ideal = _lib.layerwise_ideal_seconds(net._program().layers, rows, peak * 1e12) * 1e3
         print(f"{name} {label}: rows={rows} {fl / 1e6:.1f} MFLOP/img  {ms:.3f} ms  {fl * rows / ms / 1e9:.1f} algorithmic TFLOP/s "
-              f"({fl * rows / ms / 1e9 / peak * 100:.1f}% of the {arith} ceiling {peak:.1f})")
+              f"({fl * rows / ms / 1e9 / peak * 100:.1f}% of the {arith} ceiling {peak:.1f}); layer-wise roofline "
+              f"(each layer at the larger of its matrix time and its HBM time at 8 TB/s) {ideal:.3f} ms = {ideal / ms * 100:.1f}%")
 
 
 if __name__ == "__main__":

@@ -64,6 +64,26 @@ class cs_layer_desc(C.Structure):
                [("w_off", C.c_int64), ("b_off", C.c_int64)]
 
 
+def program_layer_costs(layers):
+    """Per layer of a layer program: (algorithmic FLOPs, algorithmic HBM bytes) per input row (image).  FLOPs:
+    2 k^2 cin cout hout wout of a convolution / linear layer.  Bytes: the float32 activations a layer must read
+    (its source image once -- the pre-upsampling image of an upsampled convolution --, the residual it adds) and
+    write; weights are shared by all rows and left out.  Used to price a network against a layer-wise roofline:
+    every layer at the larger of its matrix time and its memory time."""
+    out = []
+    for L in layers:
+        src = L.cin * min(L.hin * L.win, L.hout * L.wout * L.ksize * L.ksize)  # a strided 1x1 layer skips pixels
+        dst = L.hout * L.wout * L.cout
+        flops = 2 * L.ksize * L.ksize * L.cin * L.cout * L.hout * L.wout if L.op in (CS_OP_CONV, CS_OP_LINEAR) else 0
+        out.append((flops, 4 * (src + dst + (dst if L.res >= 0 else 0))))
+    return out
+
+
+def layerwise_ideal_seconds(layers, rows, flops_per_s, bytes_per_s=8.0e12):
+    """Sum over the layers of max(matrix time, memory time) for `rows` rows."""
+    return sum(max(f * rows / flops_per_s, b * rows / bytes_per_s) for f, b in program_layer_costs(layers))
+
+
 class cs_rng(C.Structure):
     _fields_ = [("seed", C.c_uint64), ("iteration", C.c_uint32), ("example_offset", C.c_int64)]
 

@@ -508,6 +508,33 @@ def main():
     except (OSError, ValueError):
         pass
 
+    if world == 1:
+        # Yardstick measured in this run, on this box: the vendor library's dense GEMM (torch.matmul) on random normal
+        # 8192^2 matrices, clock settled.  The split kernels execute 6 bf16 matrix FLOPs per algorithmic FLOP.
+        lib = {}
+        for name, dt, reps in (("bf16", torch.bfloat16, 40), ("f32", torch.float32, 8)):
+            ga = torch.randn(8192, 8192, device=dev).to(dt)
+            gb = torch.randn(8192, 8192, device=dev).to(dt)
+            t0 = time.perf_counter()
+            while time.perf_counter() - t0 < 0.3:
+                ga @ gb
+                torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                ga @ gb
+            e1.record()
+            torch.cuda.synchronize()
+            lib[f"{name}_tflops"] = 2 * 8192 ** 3 / (e0.elapsed_time(e1) / reps) / 1e9
+            del ga, gb
+        torch.cuda.empty_cache()
+        lib["what"] = ("torch.matmul (vendor GEMM library) on random normal 8192^2 matrices in this run; the encoder launch "
+                       "executes 6 x roofline.achieved bf16 matrix TFLOP/s" if split else
+                       "torch.matmul (vendor GEMM library) on random normal 8192^2 matrices in this run")
+        if split:
+            lib["encoder_executed_bf16_tflops"] = 6 * roofline["achieved"]
+        out["library_gemm_this_run"] = lib
+
     if not args.no_cpu_baseline and world == 1:
         # Accuracy of the arithmetic in force, measured here and now (left out, like the CPU baseline, of the
         # profiled --no-cpu-baseline runs, whose kernel statistics then hold the timed launches only): the encoder network on 4096 rows of the

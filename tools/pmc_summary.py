@@ -43,7 +43,7 @@ def main():
     # kernel (the default arithmetic), 4 tiles of 16 in the exact-f32 kernel
     # (the 16-row split kernel, the default: 4 output tiles of 16, 8-wave workgroups)
     for k, ent in out["kernels"].items():
-        if "cs_mlp_split16_kernel<16, 4, 8>" in k:
+        if "cs_mlp_split16_kernel<16, 4, 8, 3>" in k:
             out["encoder_launch"] = ent
             out["mlp_arith"] = "bf16x3"
     if "encoder_launch" not in out:

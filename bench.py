@@ -505,6 +505,12 @@ def main():
     try:
         with open(os.path.join(ROOT, "roofline.json")) as f:
             out["measured_peaks"] = json.load(f)   # what a box of this kind sustains (tools/micro/peaks.hip), for context
+        on_data = out["measured_peaks"].get("mfma_on_data", {}).get("random_operands_tflops")
+        if split and on_data:
+            # context only (`frac` stays priced on the nominal peak): what the matrix pipes alone sustain on random
+            # bf16 operands (tools/micro/mfma_data.hip), as algorithmic TFLOP/s of the 6-product arithmetic
+            roofline["matrix_pipes_on_data_tflops"] = on_data / 6.0
+            roofline["frac_of_matrix_pipes_on_data"] = roofline["achieved"] / (on_data / 6.0)
     except (OSError, ValueError):
         pass
 

@@ -112,6 +112,31 @@ def test_yaml_driver_end_to_end_lair_and_acmwg(tmp_path):
     assert int(av.min()) >= 4 and int(av.max()) <= 4 + 9 - 1
 
 
+@pytest.mark.parametrize("dataset,D", [("hepmass", 21), ("gas", 8)])
+def test_yaml_driver_whole_dataset_configs_k16(tmp_path, dataset, D):
+    """The HEPMASS / GAS configurations (K=16 chains + 1 replenishing proposal over the whole test set, last
+    iteration and 5 final-resampling imputations stored) through the YAML driver, cut down to 300 synthetic rows."""
+    from vae_conditional_sampling_amd import driver
+    cfg = driver.load_config(
+        os.path.join(ROOT, f"configs/uci_{dataset}/sampling_u50/lair_k16_dmis_gr_mult_1replenish_wholedataset.yaml"),
+        ["data.synthetic_num_test=300", "data.batch_size=128", f"trainer.default_root_dir={tmp_path}",
+         "test_class.init_args.num_iterations=7"])
+    tester, outs = driver.run(cfg)
+    f0 = np.load(os.path.join(tester.out_dir, "imputations_0.npz"))
+    B0 = f0["true_X"].shape[0]
+    # store_last_n_iterations: 1 keeps the yields t >= max_iterations - 1, i.e. the last two (the reference's rule,
+    # irwg/sampling/test_step_vae_sampling.py:386)
+    assert f0["imputations"].shape == (2, B0, 16, D) and np.isfinite(f0["imputations"]).all()
+    obs = np.broadcast_to(f0["masks"], (B0, 16, D))
+    assert np.array_equal(f0["imputations"][-1][obs], np.broadcast_to(f0["true_X"], (B0, 16, D))[obs])
+    f1 = np.load(os.path.join(tester.out_dir, "irwg_imputations_after_final_resampling_0.npz"))
+    assert f1["imputations"].shape == (1, B0, 5, D) and np.isfinite(f1["imputations"]).all()
+    assert all(0 < e <= 17 for e in outs[0]["is_ess"])
+    for name in ("rmse", "mae"):
+        v = outs[0][f"imp_metric/{name}"]
+        assert v.shape == (7, B0, 16) and np.isfinite(v).all()
+
+
 @pytest.mark.parametrize("config,extra", [
     ("configs/uci_miniboone/sampling_u50/lair_k4_dmis_gr_mult_1replenish.yaml",
      ["test_class.init_args.num_iterations=5", "test_class.init_args.store_latents=True"]),

@@ -289,3 +289,25 @@ def test_every_reference_yaml_of_the_built_sampler_classes_constructs():
         n += 1
         seen.add(name)
     assert n >= 200 and seen == built, (n, seen)
+
+
+@pytest.mark.parametrize("K", [1, 4])
+def test_pointwise_metric_summary_matches_numpy(K):
+    """The per-iteration mean / std / quantiles of a point-wise metric (test_epoch_end) against the numpy
+    formulation of the reference's aggregation (irwg/sampling/test_step_vae_sampling.py:824-858: np.quantile with
+    its default linear interpolation over all (n k) values of an iteration), ragged batches."""
+    from vae_conditional_sampling_amd.sampling.imputation_metrics import pointwise_summary
+    rs = np.random.RandomState(3)
+    T = 7
+    values = [rs.rand(T, n, K).astype(np.float32) ** 3 for n in (33, 64, 5)]
+    qs = [0.1, 0.25, 0.5, 0.75, 0.9, 0.0, 1.0]
+    mean, std, quant = pointwise_summary(values, qs)
+    v = np.concatenate(values, axis=1).transpose(1, 2, 0)          # n k t
+    over_data = v.mean(axis=0)
+    assert np.allclose(mean, over_data.mean(axis=0), rtol=1e-5, atol=1e-7)
+    ref_std = over_data.std(axis=0, ddof=1) if K != 1 else np.ones(T)
+    assert np.allclose(std, ref_std, rtol=1e-4, atol=1e-7)
+    ref_q = np.quantile(v.reshape(-1, T), axis=0, q=qs)
+    assert quant.shape == ref_q.shape and np.allclose(quant, ref_q, rtol=1e-6, atol=1e-7)
+    m2, s2, q2 = pointwise_summary(values, [])
+    assert q2.shape == (0, T) and np.allclose(m2, mean)

@@ -222,16 +222,13 @@ class TestVAESamplerBase(HyperparametersMixin):
                 continue
             if key.startswith('imp_metric/'):
                 name = key.split('imp_metric/')[1]
-                v = np.concatenate(values, axis=1).transpose(1, 2, 0)       # t n k -> n k t
-                over_data = v.mean(axis=0)                                   # k t
-                summary[f'{name}/mean/test'] = over_data.mean(axis=0)
-                summary[f'{name}/std/test'] = (over_data.std(axis=0, ddof=1) if over_data.shape[0] != 1
-                                               else np.ones_like(over_data.mean(axis=0)))
                 qs = self.hparams.imputation_metric_quantiles
-                if len(qs):
-                    quant = np.quantile(v.reshape(-1, v.shape[-1]), axis=0, q=qs)
-                    for i, q in enumerate(qs):
-                        summary[f'{name}/q{q}/test'] = quant[i]
+                dev = getattr(getattr(self, "model", None), "device", None)
+                mean, std, quant = imputation_metrics.pointwise_summary(values, qs, dev)   # values: [t, n_b, k] per batch
+                summary[f'{name}/mean/test'] = mean
+                summary[f'{name}/std/test'] = std
+                for i, q in enumerate(qs):
+                    summary[f'{name}/q{q}/test'] = quant[i]
             else:
                 m = np.array(values, dtype=np.float64)
                 summary[f'{key}/test'] = (m * num_X[:, None]).sum(axis=0) / num_X.sum()

@@ -311,3 +311,35 @@ def test_pointwise_metric_summary_matches_numpy(K):
     assert quant.shape == ref_q.shape and np.allclose(quant, ref_q, rtol=1e-6, atol=1e-7)
     m2, s2, q2 = pointwise_summary(values, [])
     assert q2.shape == (0, T) and np.allclose(m2, mean)
+
+
+def test_parallel_npz_writer_matches_numpy(tmp_path):
+    """utils.artifacts.savez_compressed_parallel / AsyncNpzWriter write the container np.savez_compressed writes:
+    np.load returns the same keys, dtypes, shapes and contents (several compression pieces and write slices, a
+    bool array, an empty list, a scalar, Fortran order)."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    from vae_conditional_sampling_amd.utils import artifacts
+    rs = np.random.RandomState(0)
+    big = np.repeat(rs.randn(3, 200000).astype(np.float32), 7, axis=0)           # 16.8 MB, compressible
+    arrays = dict(imputations=big, masks=rs.rand(50, 1, 43) > 0.5, latents=[], data_idx=np.arange(50),
+                  scalar=np.float64(2.5), fort=np.asfortranarray(rs.rand(5, 6)))
+    old_piece, old_slice = artifacts._PIECE, artifacts._SLICE
+    artifacts._PIECE, artifacts._SLICE = 1 << 20, 5 << 20                          # 17 pieces, 4 write slices
+    try:
+        with ThreadPoolExecutor(4) as pool:
+            artifacts.savez_compressed_parallel(tmp_path / "a.npz", pool, **arrays)
+    finally:
+        artifacts._PIECE, artifacts._SLICE = old_piece, old_slice
+    np.savez_compressed(tmp_path / "b.npz", **arrays)
+    w = artifacts.AsyncNpzWriter(workers=2, max_pending=2, compress_threads=3)
+    w.submit(str(tmp_path / "c.npz"), **arrays)
+    w.close()
+    ref = np.load(tmp_path / "b.npz")
+    for name in ("a.npz", "c.npz"):
+        got = np.load(tmp_path / name)
+        assert sorted(got.files) == sorted(ref.files)
+        for k in ref.files:
+            assert got[k].dtype == ref[k].dtype and got[k].shape == ref[k].shape and np.array_equal(got[k], ref[k])
+    size = lambda n: (tmp_path / n).stat().st_size
+    assert size("a.npz") < 1.1 * size("b.npz")     # independent pieces cost little compression

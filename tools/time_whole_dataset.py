@@ -15,8 +15,7 @@ tester, outs = driver.run(cfg)
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
 a = cfg["test_class"]["init_args"]
-n = sum(len(o["is_ess"][0]) if hasattr(o["is_ess"][0], "__len__") else 0 for o in outs)
-T, K = a["num_iterations"], a["num_copies"]
+T, K = a.get("num_iterations", a.get("num_mwg_iterations")), a["num_copies"]
 N = tester.datamodule.num_test_total if hasattr(tester, "datamodule") else None
 print(f"{sys.argv[1]}: {len(outs)} batches, N={N}, K={K}, T={T}: {dt:.2f} s end to end"
       + (f" = {N * K * T / dt:.3e} conditional samples/s including set-up, diagnostics and artefact files" if N else ""))

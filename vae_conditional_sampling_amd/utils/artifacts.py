@@ -7,27 +7,82 @@ takes several times longer than the whole sampling loop of the batch on the GPU,
 written by a small pool of host threads (zlib releases the GIL) while the next batch is sampled.
 File names, keys and contents are unchanged.  At most ``max_pending`` files are in flight (their
 arrays are held in host memory until written).
+
+One file is mostly one array (``imputations``), so a thread per file still leaves each file to a single core
+for a minute: ``savez_compressed_parallel`` writes the same zip container (deflate members, readable by
+``np.load``) with every member's deflate stream produced in independent pieces on a pool of threads, the way
+parallel gzip implementations do (each piece a raw deflate run closed by a full flush, an empty final block at
+the end: the concatenation is one valid stream).
 """
+import os
 import threading
+import zipfile
+import zlib
 from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 
+_PIECE = 4 << 20          # bytes compressed per task
+_SLICE = 64 * _PIECE      # bytes handed to one write() call
+
+
+class _PieceDeflate:
+    """Stands in for the compressor object of an open zip member: ``compress`` deflates its input in
+    independent ``_PIECE``-sized pieces on the pool, ``flush`` closes the stream."""
+
+    def __init__(self, pool, level):
+        self._pool, self._level = pool, level
+
+    def _one(self, piece):
+        c = zlib.compressobj(self._level, zlib.DEFLATED, -15)
+        return c.compress(piece) + c.flush(zlib.Z_FULL_FLUSH)
+
+    def compress(self, data):
+        mv = memoryview(data)
+        return b"".join(self._pool.map(self._one, [mv[i:i + _PIECE] for i in range(0, len(mv), _PIECE)]))
+
+    def flush(self):
+        return zlib.compressobj(self._level, zlib.DEFLATED, -15).flush(zlib.Z_FINISH)
+
+
+def savez_compressed_parallel(path, pool, level=6, **arrays):
+    """``np.savez_compressed(path, **arrays)`` with the compression of every member spread over ``pool``."""
+    path = os.fspath(path)
+    if not path.endswith(".npz"):
+        path += ".npz"
+    with zipfile.ZipFile(path, "w", compression=zipfile.ZIP_DEFLATED, allowZip64=True) as zf:
+        for key, val in arrays.items():
+            arr = np.asanyarray(val)
+            with zf.open(key + ".npy", "w", force_zip64=True) as f:
+                if arr.dtype.hasobject or getattr(f, "_compressor", None) is None:
+                    np.lib.format.write_array(f, arr, allow_pickle=True)     # numpy's own path
+                    continue
+                f._compressor = _PieceDeflate(pool, level)
+                arr = arr if arr.flags.c_contiguous else np.ascontiguousarray(arr)   # (keeps 0-d arrays 0-d)
+                np.lib.format.write_array_header_1_0(f, np.lib.format.header_data_from_array_1_0(arr))
+                raw = memoryview(arr.reshape(-1)).cast("B") if arr.size else memoryview(b"")
+                for i in range(0, len(raw), _SLICE):
+                    f.write(raw[i:i + _SLICE])
+
 
 class AsyncNpzWriter:
-    def __init__(self, workers=4, max_pending=4):
+    def __init__(self, workers=4, max_pending=4, compress_threads=None):
         self._pool = ThreadPoolExecutor(max_workers=workers, thread_name_prefix="npz-writer")
+        # threads that deflate the pieces of the files being written (zlib releases the GIL); OMP_NUM_THREADS is
+        # the CPU share of a process on a shared host
+        n = compress_threads or max(1, min(16, int(os.environ.get("OMP_NUM_THREADS", 0)) or (os.cpu_count() or 1)))
+        self._deflate_pool = ThreadPoolExecutor(max_workers=n, thread_name_prefix="npz-deflate")
         self._slots = threading.Semaphore(max_pending)
         self._futures = []
 
     def submit(self, path, **arrays):
-        """``np.savez_compressed(path, **arrays)`` on a worker thread; blocks while ``max_pending``
-        earlier files are still being written."""
+        """``np.savez_compressed(path, **arrays)`` (its parallel form) on a worker thread; blocks while
+        ``max_pending`` earlier files are still being written."""
         self._slots.acquire()
 
         def job():
             try:
-                np.savez_compressed(path, **arrays)
+                savez_compressed_parallel(path, self._deflate_pool, **arrays)
             finally:
                 self._slots.release()
         self._futures.append(self._pool.submit(job))
@@ -41,3 +96,4 @@ class AsyncNpzWriter:
     def close(self):
         self.wait()
         self._pool.shutdown(wait=True)
+        self._deflate_pool.shutdown(wait=True)

@@ -51,6 +51,9 @@ SPLIT_PEAK_TFLOPS = BF16_MFMA_PEAK_TFLOPS / 6.0
 # algorithmic FLOPs per image of the ConvResNet encoders / decoders (2 k^2 cin cout hout wout per convolution,
 # 2 in out per linear layer)
 CONV_FLOPS = {"omniglot": (911693824, 1230915584), "mnist_gmm": (60988672, 113640448)}
+# CSVAE_BENCH_REHEARSAL=1: a rehearsal of the multi-rank control flow on a box with ONE GPU -- every rank computes on
+# GPU 0 and the collectives run over gloo on host copies.  Its JSON line says so ("rehearsal") and is no measurement.
+REHEARSAL = os.environ.get("CSVAE_BENCH_REHEARSAL") == "1"
 SEED = 20220118
 SETTLE_S = 0.4   # seconds of untimed load before the warm-up steps (clock settle)
 BASE_KW = dict(store_last_n_iterations=-1, store_every_n_iterations=1, imputation_metric_quantiles=[],
@@ -73,6 +76,8 @@ def launch_ranks(n):
     import socket
     import subprocess
     have = torch.cuda.device_count()   # counts devices without initialising the GPU runtime
+    if REHEARSAL and have >= 1:
+        have = n                       # rehearsal: every rank uses GPU 0 (see REHEARSAL)
     if have < n:
         print(f"bench.py: --gpus {n} but only {have} GPU(s) are visible; not reporting a smaller run in its place",
               file=sys.stderr)
@@ -410,12 +415,17 @@ def main():
         raise SystemExit(launch_ranks(args.gpus))
     if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if REHEARSAL:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if REHEARSAL:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     from vae_conditional_sampling_amd import _lib
 
@@ -431,15 +441,20 @@ def main():
 
     elapsed, evs = bench.timed(args.steps, args.warmup, dist)
     if dist is not None:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        cdev = torch.device("cpu") if REHEARSAL else dev   # gloo collectives take host tensors
+        tt = torch.tensor([elapsed], device=cdev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
         # the only collective of the path: final imputations and log-weights are gathered once
-        gathered = torch.empty(world, *bench.X.shape, device=dev)
-        dist.all_gather_into_tensor(gathered, bench.X)
-        glw = torch.empty(world, *bench.ws.log_w.shape, device=dev)
-        dist.all_gather_into_tensor(glw, bench.ws.log_w)
+        # (outputs in the concatenated form [world * n, ...], which every backend accepts)
+        Xl, lwl = bench.X.to(cdev), bench.ws.log_w.reshape(-1).to(cdev)
+        gathered = torch.empty(world * Xl.shape[0], *Xl.shape[1:], device=cdev)
+        dist.all_gather_into_tensor(gathered, Xl)
+        glw = torch.empty(world * lwl.shape[0], device=cdev)
+        dist.all_gather_into_tensor(glw, lwl)
         torch.cuda.synchronize()
+        assert torch.equal(gathered[rank * Xl.shape[0]:(rank + 1) * Xl.shape[0]], Xl) and torch.isfinite(glw).all(), \
+            "gathered shard differs"
     assert torch.isfinite(bench.X).all(), "non-finite imputations"
 
     if rank != 0:
@@ -498,6 +513,9 @@ def main():
         "roofline": roofline,
         "kernels": kernels,
     }
+    if REHEARSAL:
+        out["rehearsal"] = (f"{world} ranks sharing GPU 0, collectives over gloo: a rehearsal of the multi-rank control flow, "
+                            "NOT a multi-GPU measurement")
     if exact is not None:
         out["exact_f32"] = exact
     if plain is not None:

@@ -343,3 +343,24 @@ def test_parallel_npz_writer_matches_numpy(tmp_path):
             assert got[k].dtype == ref[k].dtype and got[k].shape == ref[k].shape and np.array_equal(got[k], ref[k])
     size = lambda n: (tmp_path / n).stat().st_size
     assert size("a.npz") < 1.1 * size("b.npz")     # independent pieces cost little compression
+
+
+def test_sharded_artifact_merge_passes_switched_off_entries_through(tmp_path):
+    """An option that is off is stored as an empty list in the artefact files (``latents`` without
+    ``store_latents``), also where the example axis of that key is 0 (final-resampling files): merging shards,
+    gathering them and cutting them into the one-process batches must hand such an entry on unchanged, while a rank
+    without examples still contributes its (empty) per-example arrays."""
+    from vae_conditional_sampling_amd import distributed as D
+    stem = "irwg_imputations_after_final_resampling"
+    mk = lambda lo, hi: {stem: dict(imputations=np.arange(lo, hi, dtype=np.float32)[None, :, None, None] + np.zeros((1, 1, 3, 2), np.float32),
+                                    latents=np.asarray([]), true_X=np.zeros((hi - lo, 1, 2), np.float32),
+                                    masks=np.ones((hi - lo, 1, 2), bool), data_idx=np.arange(lo, hi))}
+    merged = D.merge_shards([mk(0, 5), mk(5, 5), mk(5, 9)])          # the middle rank holds no example
+    assert merged[stem]["latents"].shape == (0,) and merged[stem]["imputations"].shape == (1, 9, 3, 2)
+    assert np.array_equal(merged[stem]["data_idx"], np.arange(9))
+    same = D.gather_shard_arrays(mk(0, 9), 9, "cpu")                 # no process group: the identity
+    assert same[stem]["latents"].shape == (0,) and same[stem]["imputations"].shape == (1, 9, 3, 2)
+    paths = D.write_batches(merged, 4, str(tmp_path), save=np.savez)
+    assert len(paths) == 3
+    f = np.load(paths[2])
+    assert f["latents"].shape == (0,) and f["imputations"].shape == (1, 1, 3, 2) and f["data_idx"].tolist() == [8]

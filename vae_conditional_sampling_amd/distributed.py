@@ -29,6 +29,13 @@ EXAMPLE_AXIS = {
 }
 
 
+def _is_placeholder(key, a, ax):
+    """An option that is off is stored as an empty list (e.g. ``latents`` without ``store_latents``): such an entry
+    has no example axis and is passed through as it is.  (``data_idx`` is the one genuinely 1-d per-example array:
+    empty only on a rank without examples.)"""
+    return a.ndim <= ax or (a.ndim == 1 and a.size == 0 and key != "data_idx")
+
+
 def group_ready():
     return dist.is_available() and dist.is_initialized()
 
@@ -76,8 +83,7 @@ def _concat(dicts, stem):
     for key in dicts[0]:
         ax = EXAMPLE_AXIS[stem][key]
         parts = [d[key] for d in dicts]
-        # an option that is off is stored as an empty list (e.g. latents without store_latents)
-        merged[key] = parts[0] if parts[0].ndim <= ax else np.concatenate(parts, axis=ax)
+        merged[key] = parts[0] if _is_placeholder(key, parts[0], ax) else np.concatenate(parts, axis=ax)
     return merged
 
 
@@ -95,7 +101,7 @@ def gather_shard_arrays(shard, n_total, device, group=None):
         for key in sorted(shard[stem]):
             a = shard[stem][key]
             ax = EXAMPLE_AXIS[stem][key]
-            if a.ndim <= ax:
+            if _is_placeholder(key, a, ax):
                 out[stem][key] = a
                 continue
             t = torch.from_numpy(np.ascontiguousarray(np.moveaxis(a, ax, 0)))
@@ -118,7 +124,8 @@ def write_batches(merged, batch_size, out_dir, save=np.savez_compressed):
             part = {}
             for key, a in arrays.items():
                 ax = EXAMPLE_AXIS[stem][key]
-                part[key] = a if a.ndim <= ax else np.take(a, np.arange(lo, min(lo + int(batch_size), n)), axis=ax)
+                part[key] = (a if _is_placeholder(key, a, ax)
+                             else np.take(a, np.arange(lo, min(lo + int(batch_size), n)), axis=ax))
             path = os.path.join(out_dir, f"{stem}_{b}.npz")
             save(path, **part)
             paths.append(path)

@@ -108,7 +108,7 @@ def find_checkpoint(model_path, load_best):
     return path
 
 
-def run(cfg, *, device=None, rank=0, world_size=1):
+def run(cfg, *, device=None, rank=0, world_size=1, gather_device=None):
     torch.manual_seed(int(cfg["seed_everything"]))
     device = device or torch.device("cuda", torch.cuda.current_device())
     trainer = cfg.get("trainer") or {}
@@ -154,7 +154,8 @@ def run(cfg, *, device=None, rank=0, world_size=1):
             tester.on_test_batch_end(out, batch, batch_idx, 0)
             outputs.append(out)
             offset += batch[0].shape[0]
-    finish_run(tester, outputs, datamodule.num_test_total, datamodule.hparams.batch_size, rank, sharded, device)
+    finish_run(tester, outputs, datamodule.num_test_total, datamodule.hparams.batch_size, rank, sharded,
+               gather_device or device)
     return tester, outputs
 
 
@@ -201,12 +202,20 @@ def main(argv=None):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise RuntimeError("no GPU visible: the sampling path runs in HIP kernels only (no CPU fallback)")
+    # CSVAE_DIST_REHEARSAL=1: the multi-process flow on a box with one GPU -- every rank computes on GPU 0 and the
+    # final gathers run over gloo on host copies (a check of the control flow, not a way to run faster)
+    rehearsal = os.environ.get("CSVAE_DIST_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     try:
-        run(cfg, rank=rank, world_size=world)
+        run(cfg, rank=rank, world_size=world, gather_device=torch.device("cpu") if rehearsal else None)
     finally:
         if world > 1:
             import torch.distributed as dist

@@ -66,8 +66,14 @@ def resfc_flops(i, H, nb, o):
     return 2 * (i * H + 2 * nb * H * H + H * o)
 
 
+# the fp16 split forms a float32 product from 3 fp16 term products (dense fp16 matrix peak = the bf16 one)
+F16X2_PEAK_TFLOPS = BF16_MFMA_PEAK_TFLOPS / 3.0
+DTYPES = {"bf16x3": "f32 as 3 bf16 terms per operand, f32 accumulation", "f16x2": "f32 as 2 fp16 terms per operand, f32 accumulation",
+          "f32": "f32"}
+
+
 def peak_of(arith):
-    return {"bf16x3": SPLIT_PEAK_TFLOPS, "bf16": BF16_MFMA_PEAK_TFLOPS}.get(arith, F32_MFMA_PEAK_TFLOPS)
+    return {"bf16x3": SPLIT_PEAK_TFLOPS, "f16x2": F16X2_PEAK_TFLOPS, "bf16": BF16_MFMA_PEAK_TFLOPS}.get(arith, F32_MFMA_PEAK_TFLOPS)
 
 
 def launch_ranks(n):
@@ -215,12 +221,15 @@ class LairCabi:
         res_bytes = (Kp * 2 * Zd * 4 + Kp * Zd * 4 + Kp * 4 + K * (2 * D * 4 + D * 4) + D) + (K * D * 4 + 2 * Kp * 4 + Kp * 8 + 12)
         split = arith == "bf16x3"
         roofline = {"bound": "mfma", "kernel": ((("cs_mlp_split_kernel" if os.environ.get("CSVAE_SPLIT_TILE") == "32" else "cs_mlp_split16_kernel")
-                                                 if split else "cs_mlp_split16_kernel<TERMS=1>" if arith == "bf16" else "cs_mlp_kernel")
+                                                 if split else "cs_mlp_split16_kernel<TERMS=1>" if arith == "bf16"
+                                                 else "cs_mlp_split16_kernel<TERMS=2>" if arith == "f16x2" else "cs_mlp_kernel")
                                                 + " (encoder launch)"),
                     "achieved": enc_tf, "peak": peak, "unit": "TFLOP/s", "frac": enc_tf / peak,
                     "traffic": None, "flops_per_launch": enc_flops, "avg_launch_ms": enc_ms,
                     "note": ("algorithmic float32 FLOPs; each is executed as 6 bf16 matrix FLOPs, so peak = dense bf16 "
                              "peak 2500 / 6 and the executed bf16 rate is 6 x achieved") if split else
+                            ("algorithmic float32 FLOPs; each is executed as 3 fp16 matrix FLOPs, so peak = dense fp16 "
+                             "peak 2500 / 3 and the executed fp16 rate is 3 x achieved") if arith == "f16x2" else
                             "operands rounded to bf16, one bf16 matrix FLOP per algorithmic FLOP: peak = dense bf16 peak" if arith == "bf16" else
                             "algorithmic float32 FLOPs on the exact-f32 matrix instructions"}
         kernels = {"encoder_ms": enc_ms, "decoder_ms": dec_ms, "resample_impute_ms": res_ms,
@@ -403,7 +412,7 @@ def main():
     ap.add_argument("--batch", type=int, default=65536, help="examples per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="only the headline workload (no `extra` legs)")
-    ap.add_argument("--arith", default=None, choices=["bf16x3", "f32"],
+    ap.add_argument("--arith", default=None, choices=["bf16x3", "f16x2", "f32"],
                     help="arithmetic of the fused MLP kernel (default: the library's, bf16x3 = exact 3-way bf16 split of "
                          "the float32 operands, float32 accumulation, float32-equivalent results)")
     args = ap.parse_args()
@@ -475,16 +484,19 @@ def main():
     except (OSError, KeyError, ValueError):
         pass
 
-    # the same K steps on the exact-float32 matrix instructions, for comparison (outside the timed region)
-    exact = None
-    if arith != "f32" and world == 1:
-        _lib.set_mlp_arith("f32")
-        el, evs32 = bench.timed(args.steps, args.warmup)
-        r32, k32 = bench.kernel_report(evs32, "f32")
+    # the same K steps in the other float32-equivalent arithmetics, for comparison (outside the timed region)
+    others = {}
+    if world == 1:
+        for name, key in (("f32", "exact_f32"), ("bf16x3", "split_bf16x3"), ("f16x2", "split_f16x2")):
+            if name == arith:
+                continue
+            _lib.set_mlp_arith(name)
+            el, evo = bench.timed(args.steps, args.warmup)
+            ro, ko = bench.kernel_report(evo, name)
+            others[key] = {"value": B * K * args.steps / el, "ms_per_step": el / args.steps * 1e3, "unit": "samples/s", "dtype": DTYPES[name],
+                           "roofline": {k: ro[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "flops_per_launch", "avg_launch_ms")},
+                           "kernels": {k: ko[k] for k in ("encoder_ms", "decoder_ms", "resample_impute_ms", "decoder_frac", "step_mfma_frac")}}
         _lib.set_mlp_arith(arith)
-        exact = {"value": B * K * args.steps / el, "ms_per_step": el / args.steps * 1e3, "unit": "samples/s",
-                 "roofline": {k: r32[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "flops_per_launch", "avg_launch_ms")},
-                 "kernels": {k: k32[k] for k in ("encoder_ms", "decoder_ms", "resample_impute_ms", "decoder_frac", "step_mfma_frac")}}
 
     # and in the opt-in plain-bf16 mode (operands ROUNDED to bf16: reduced precision, never the headline)
     plain = None
@@ -501,12 +513,13 @@ def main():
                  "kernels": {k: kb[k] for k in ("encoder_ms", "decoder_ms", "resample_impute_ms", "decoder_frac", "step_mfma_frac")}}
 
     value = world * B * K * args.steps / elapsed
-    split = arith == "bf16x3"
+    nprod = {"bf16x3": 6, "f16x2": 3}.get(arith)   # 16-bit matrix FLOPs executed per algorithmic FLOP
+    split = nprod is not None
     out = {
         "metric": "conditional samples/sec (N x K chains) for LAIR",
         "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "clock_settle_s": SETTLE_S,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32 as 3 bf16 terms per operand, f32 accumulation" if split else "f32", "data": "synthetic",
+        "vs_baseline": None, "dtype": DTYPES[arith], "data": "synthetic",
         "config": {"workload": f"uci_{args.workload} MLP-VAE LAIR (dmis/gr/multinomial), D={D} Zd={Zd} H={H} "
                                f"enc_blocks={w['nbe']} dec_blocks={w['nbd']} K={K} R={R} I=1",
                    "examples_per_gpu": B, "chains_per_gpu": B * K, "sharding": f"examples x{world}, no collective in loop"},
@@ -516,8 +529,7 @@ def main():
     if REHEARSAL:
         out["rehearsal"] = (f"{world} ranks sharing GPU 0, collectives over gloo: a rehearsal of the multi-rank control flow, "
                             "NOT a multi-GPU measurement")
-    if exact is not None:
-        out["exact_f32"] = exact
+    out.update(others)
     if plain is not None:
         out["plain_bf16"] = plain
     try:
@@ -526,9 +538,9 @@ def main():
         on_data = out["measured_peaks"].get("mfma_on_data", {}).get("random_operands_tflops")
         if split and on_data:
             # context only (`frac` stays priced on the nominal peak): what the matrix pipes alone sustain on random
-            # bf16 operands (tools/micro/mfma_data.hip), as algorithmic TFLOP/s of the 6-product arithmetic
-            roofline["matrix_pipes_on_data_tflops"] = on_data / 6.0
-            roofline["frac_of_matrix_pipes_on_data"] = roofline["achieved"] / (on_data / 6.0)
+            # bf16 operands (tools/micro/mfma_data.hip), as algorithmic TFLOP/s of this arithmetic's product count
+            roofline["matrix_pipes_on_data_tflops"] = on_data / nprod
+            roofline["frac_of_matrix_pipes_on_data"] = roofline["achieved"] / (on_data / nprod)
     except (OSError, ValueError):
         pass
 
@@ -552,11 +564,11 @@ def main():
             lib[f"{name}_tflops"] = 2 * 8192 ** 3 / (e0.elapsed_time(e1) / reps) / 1e9
             del ga, gb
         torch.cuda.empty_cache()
-        lib["what"] = ("torch.matmul (vendor GEMM library) on random normal 8192^2 matrices in this run; the encoder launch "
-                       "executes 6 x roofline.achieved bf16 matrix TFLOP/s" if split else
+        lib["what"] = (f"torch.matmul (vendor GEMM library) on random normal 8192^2 matrices in this run; the encoder launch "
+                       f"executes {nprod} x roofline.achieved 16-bit matrix TFLOP/s" if split else
                        "torch.matmul (vendor GEMM library) on random normal 8192^2 matrices in this run")
         if split:
-            lib["encoder_executed_bf16_tflops"] = 6 * roofline["achieved"]
+            lib["encoder_executed_16bit_tflops"] = nprod * roofline["achieved"]
         out["library_gemm_this_run"] = lib
 
     if not args.no_cpu_baseline and world == 1:
@@ -574,13 +586,13 @@ def main():
         xs = bench.X[:1024].reshape(-1, D).contiguous()
         y64 = forward64(bench.enc_w, xs.cpu().double())
         acc = {}
-        for name in ("bf16x3", "f32"):
+        for name in ("bf16x3", "f16x2", "f32"):
             _lib.set_mlp_arith(name)
             y = bench.model.var_latent_network(xs).cpu().double()
             acc[name] = float((y - y64).abs().max() / y64.abs().max())
         _lib.set_mlp_arith(arith)
         out["accuracy"] = {"what": "encoder outputs, 4096 rows, max |y - y_float64| / max |y_float64|",
-                           "bf16x3": acc["bf16x3"], "exact_f32": acc["f32"]}
+                           "bf16x3": acc["bf16x3"], "f16x2": acc["f16x2"], "exact_f32": acc["f32"]}
 
     enc_w, dec_w, Xs, Ms = bench.enc_w, bench.dec_w, bench.X[:512].cpu(), bench.M[:512]
     if not args.no_extras and world == 1:

@@ -434,10 +434,17 @@ int cs_rng_uniform64(const cs_rng* rng, uint32_t stream_id, int64_t rows, int32_
  *                    a relative rounding error of up to 2^-9; results follow a bfloat16-rounded evaluation of
  *                    the network (tests/test_gpu_bf16_arith.py), not the reference's float32 one.  Fused MLP
  *                    kernel only; layer-program networks keep CS_ARITH_BF16X3 under this setting.
+ *   CS_ARITH_F16X2   experimental, opt-in: every float32 operand as two fp16 terms (11 + 11 significand bits),
+ *                    three products per pair, float32 accumulation: half the matrix work of CS_ARITH_BF16X3.  The
+ *                    neglected term is below 2^-22 |a||b|; against a float64 evaluation the error is within a small
+ *                    factor of the float32 kernels' (tests/test_gpu_f16x2_arith.py) for operands of ordinary size.
+ *                    fp16 has 5 exponent bits: activations beyond 65504 in magnitude are wrong (saturated, not
+ *                    flagged), a network with such a weight is refused, and operands far below 1 lose relative
+ *                    accuracy in their low-order term (kept to 2^-24 absolute).  Fused MLP kernel only.
  * The setting is process-wide and applies to launches made after the call; the environment variable
- * CSVAE_MLP_ARITH (bf16x3 | f32 | bf16) gives the initial value.  It also selects the kernels of the matrix-core
+ * CSVAE_MLP_ARITH (bf16x3 | f32 | bf16 | f16x2) gives the initial value.  It also selects the kernels of the matrix-core
  * convolution / linear layers of layer-program networks (cs_net_create). */
-enum { CS_ARITH_DEFAULT = -1, CS_ARITH_F32 = 0, CS_ARITH_BF16X3 = 1, CS_ARITH_BF16 = 2 };
+enum { CS_ARITH_DEFAULT = -1, CS_ARITH_F32 = 0, CS_ARITH_BF16X3 = 1, CS_ARITH_BF16 = 2, CS_ARITH_F16X2 = 3 };
 int cs_set_mlp_arith(int arith);
 int cs_get_mlp_arith(void);
 /* The same choice per network handle (fused MLP or layer program): it overrides the process-wide setting for

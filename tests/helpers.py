@@ -119,10 +119,11 @@ def make_conv_model(net, enc_w, dec_w, latent_dist, gen_dist, device="cuda"):
 
 def arith_fixture():
     """Autouse fixture for the MLP parity modules: every test runs once per arithmetic of the fused MLP
-    kernel (exact float32 matrix instructions, and the float32-equivalent 3-way bfloat16 split)."""
+    kernel (exact float32 matrix instructions, the float32-equivalent 3-way bfloat16 split, and the 2-way fp16
+    split)."""
     import pytest
 
-    @pytest.fixture(autouse=True, params=["f32", "bf16x3"])
+    @pytest.fixture(autouse=True, params=["f32", "bf16x3", "f16x2"])
     def mlp_arith(request):
         from vae_conditional_sampling_amd import _lib
         prev = _lib.set_mlp_arith(request.param)

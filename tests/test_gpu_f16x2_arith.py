@@ -1,0 +1,83 @@
+"""GPU tests of the experimental fp16-split arithmetic of the fused MLP kernel (CS_ARITH_F16X2, opt-in).
+
+Every float32 operand is split into two fp16 terms (11 + 11 significand bits) and a product is accumulated in
+float32 from three term products; the neglected term is below 2^-22 |a||b|.  Checked like the default arithmetic:
+against a float64 evaluation of the same network its error must be of the size of the float32 evaluations' own
+rounding error -- for operands of ordinary size.  fp16 has 5 exponent bits, so the second test documents what
+happens away from that: inputs scaled far down lose relative accuracy gracefully (the low-order term turns
+subnormal), and nothing here is pinned by a fixture of the reference ("parity unpinned")."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def to64(w):
+    f = lambda t: t.double()
+    return {"W0": f(w["W0"]), "b0": f(w["b0"]), "blocks": [tuple(f(t) for t in b) for b in w["blocks"]],
+            "Wf": f(w["Wf"]), "bf": f(w["bf"])}
+
+
+def _errors(shape, x_scale=1.5):
+    from oracle import cs_oracle as O
+    from vae_conditional_sampling_amd.models import ResidualFCNetwork
+    in_dim, out_dim, nb, H, rows = shape
+    w = O.make_resfc_weights(in_dim, out_dim, nb, H, seed=in_dim + rows)
+    net = ResidualFCNetwork(in_dim, out_dim, nb, H).load_weight_dict(w).cuda().eval()
+    x = torch.randn(rows, in_dim, generator=torch.Generator().manual_seed(5)) * x_scale
+    y64 = O.resfc_forward(to64(w), x.double())
+    out = {}
+    for arith in ("f32", "bf16x3", "f16x2"):
+        net.packed().set_arith(arith)
+        assert net.packed().get_arith() == arith
+        out[arith] = net(x.cuda()).cpu().double()
+    net.packed().set_arith(None)
+    scale = y64.abs().max()
+    err = {k: float((v - y64).abs().max() / scale) for k, v in out.items()}
+    err["cpu32"] = float((O.resfc_forward(w, x).double() - y64).abs().max() / scale)
+    return err, out
+
+
+@pytest.mark.parametrize("shape", [(43, 64, 5, 256, 4096), (32, 86, 2, 256, 4096), (21, 32, 2, 256, 1000),
+                                   (8, 32, 1, 128, 777), (70, 128, 0, 64, 333), (11, 10, 2, 64, 37), (43, 64, 5, 256, 40000)])
+def test_fp16_split_is_float32_sized_error(shape):
+    err, out = _errors(shape)
+    print(f"shape {shape}: max error / max|y| vs float64: f16x2 {err['f16x2']:.2e}, bf16x3 {err['bf16x3']:.2e}, "
+          f"exact f32 {err['f32']:.2e}, torch CPU float32 {err['cpu32']:.2e}")
+    assert err["f16x2"] < 3e-6
+    assert err["f16x2"] <= 4 * max(err["f32"], err["cpu32"]) + 2e-7
+    assert not torch.equal(out["f16x2"], out["bf16x3"])          # it is its own kernel
+
+
+@pytest.mark.parametrize("x_scale", [1e-3, 30.0])
+def test_fp16_split_away_from_unit_scale(x_scale):
+    err, _ = _errors((43, 64, 5, 256, 2048), x_scale)
+    print(f"input scale {x_scale}: f16x2 {err['f16x2']:.2e}, bf16x3 {err['bf16x3']:.2e}, exact f32 {err['f32']:.2e}")
+    assert err["f16x2"] < 1e-5
+
+
+def test_fp16_split_fails_loudly_outside_its_range():
+    """An activation beyond fp16's range poisons its row (inf / NaN in the outputs of that row only) instead of being
+    saturated silently, and a network with a weight beyond the range is refused for this arithmetic."""
+    from oracle import cs_oracle as O
+    from vae_conditional_sampling_amd import _lib
+    from vae_conditional_sampling_amd.models import ResidualFCNetwork
+    w = O.make_resfc_weights(43, 64, 2, 256, seed=4)
+    net = ResidualFCNetwork(43, 64, 2, 256).load_weight_dict(w).cuda().eval()
+    x = torch.randn(64, 43, generator=torch.Generator().manual_seed(1))
+    x[7, 3] = 1.0e5
+    net.packed().set_arith("f16x2")
+    y = net(x.cuda()).cpu()
+    net.packed().set_arith("bf16x3")
+    y3 = net(x.cuda()).cpu()
+    assert not torch.isfinite(y[7]).all()
+    ok = [i for i in range(64) if i != 7]
+    assert torch.isfinite(y[ok]).all() and torch.allclose(y[ok], y3[ok], rtol=1e-5, atol=1e-5)
+    assert torch.isfinite(y3).all()                      # the bf16 split has float32's range
+    w["W0"][0, 0] = 7.0e4
+    big = ResidualFCNetwork(43, 64, 2, 256).load_weight_dict(w).cuda().eval()
+    big.packed().set_arith("f16x2")
+    with pytest.raises(_lib.CsError, match="range of fp16"):
+        big(x.cuda())
+    big.packed().set_arith(None)
+    assert torch.isfinite(big(torch.randn(8, 43).cuda())).all()

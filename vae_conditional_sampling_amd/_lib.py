@@ -191,7 +191,7 @@ def lib():
     return L
 
 
-CS_ARITH = {"f32": 0, "bf16x3": 1, "bf16": 2}
+CS_ARITH = {"f32": 0, "bf16x3": 1, "bf16": 2, "f16x2": 3}
 
 
 def set_mlp_arith(name):

@@ -25,6 +25,7 @@ struct CsMlpDev {
   // bias table and output tile geometry are those of the exact-f32 kernel (bias, nto, tph)
   const f32x4* wstream16;
   const f32x4* wstream16b;  // the same order with one term, the weights rounded to bf16 (CS_ARITH_BF16)
+  const f32x4* wstream16h;  // the same order with two fp16 terms (CS_ARITH_F16X2); null when a weight exceeds fp16's range
   int arith;             // CS_ARITH_* of this network, or -1: the process default (cs_set_mlp_arith)
 };
 
@@ -38,6 +39,7 @@ struct cs_mlp {
   void* d_b3;
   void* d_w16;
   void* d_w16b;
+  void* d_w16h;
   int device;
   CsProgram* prog;  // layer-program networks (cs_net_create); null for the fused MLP
 };

@@ -12,6 +12,7 @@
 #include "cs_mlp.h"
 #include "cs_net.h"
 
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -54,19 +55,22 @@ static int g_arith = -1;
 int cs_mlp_arith() {
   if (g_arith < 0) {
     const char* e = std::getenv("CSVAE_MLP_ARITH");
-    g_arith = (e && std::strcmp(e, "f32") == 0) ? CS_ARITH_F32 : (e && std::strcmp(e, "bf16") == 0) ? CS_ARITH_BF16 : CS_ARITH_BF16X3;
+    g_arith = (e && std::strcmp(e, "f32") == 0) ? CS_ARITH_F32 : (e && std::strcmp(e, "bf16") == 0) ? CS_ARITH_BF16
+            : (e && std::strcmp(e, "f16x2") == 0) ? CS_ARITH_F16X2 : CS_ARITH_BF16X3;
   }
   return g_arith;
 }
 extern "C" int cs_set_mlp_arith(int arith) {
-  CS_REQUIRE(arith == CS_ARITH_F32 || arith == CS_ARITH_BF16X3 || arith == CS_ARITH_BF16, "unknown arithmetic");
+  CS_REQUIRE(arith == CS_ARITH_F32 || arith == CS_ARITH_BF16X3 || arith == CS_ARITH_BF16 || arith == CS_ARITH_F16X2,
+             "unknown arithmetic");
   g_arith = arith;
   return CS_OK;
 }
 extern "C" int cs_get_mlp_arith(void) { return cs_mlp_arith(); }
 extern "C" int cs_mlp_set_arith(cs_mlp_t* net, int arith) {
   CS_REQUIRE(net, "null argument");
-  CS_REQUIRE(arith == CS_ARITH_DEFAULT || arith == CS_ARITH_F32 || arith == CS_ARITH_BF16X3 || arith == CS_ARITH_BF16,
+  CS_REQUIRE(arith == CS_ARITH_DEFAULT || arith == CS_ARITH_F32 || arith == CS_ARITH_BF16X3 || arith == CS_ARITH_BF16 ||
+                 arith == CS_ARITH_F16X2,
              "unknown arithmetic");
   net->dev.arith = arith;
   if (net->prog) net->prog->arith = arith;
@@ -106,9 +110,14 @@ int cs_mlp_launch(const CsMlpArgs& a_in, hipStream_t stream) {
   cs_split_cfg();
   const int arith = a.net.arith >= 0 ? a.net.arith : cs_mlp_arith();
   const int waves16 = g_split16_waves ? g_split16_waves : (a.rows <= 20480 ? 4 : 8);
-  const bool tile16 = arith == CS_ARITH_BF16 ||
+  const bool tile16 = arith == CS_ARITH_BF16 || arith == CS_ARITH_F16X2 ||
                       (arith == CS_ARITH_BF16X3 && g_split_tile != 32 && cs_split16_fits(a.net, waves16, 3));
   if (arith == CS_ARITH_BF16) CS_REQUIRE(cs_split16_fits(a.net, waves16, 1), "network does not fit the LDS budget");
+  if (arith == CS_ARITH_F16X2) {
+    CS_REQUIRE(cs_split16_fits(a.net, waves16, 2), "network does not fit the LDS budget");
+    CS_REQUIRE(a.net.wstream16h != nullptr, "a weight of this network exceeds the range of fp16: no fp16-split arithmetic");
+  }
+  const int terms16 = arith == CS_ARITH_BF16 ? 1 : (arith == CS_ARITH_F16X2 ? 2 : 3);
   if (a.mode == CS_MLP_DEC && a.in == nullptr &&
       (a.latent_dist == CS_DIST_BETA || (arith == CS_ARITH_BF16X3 && !tile16))) {
     // Beta proposals are drawn by a kernel of their own; the fused kernel then reads Z as its input.
@@ -125,9 +134,9 @@ int cs_mlp_launch(const CsMlpArgs& a_in, hipStream_t stream) {
     CS_REQUIRE(a.net.split == 2, "generator output must be (loc | scale)");
   if (tile16) {
     switch (a.net.nt) {
-      case 4: return cs_mlp_split16_launch_h64(a, stream, waves16, arith == CS_ARITH_BF16 ? 1 : 3);
-      case 8: return cs_mlp_split16_launch_h128(a, stream, waves16, arith == CS_ARITH_BF16 ? 1 : 3);
-      case 16: return cs_mlp_split16_launch_h256(a, stream, waves16, arith == CS_ARITH_BF16 ? 1 : 3);
+      case 4: return cs_mlp_split16_launch_h64(a, stream, waves16, terms16);
+      case 8: return cs_mlp_split16_launch_h128(a, stream, waves16, terms16);
+      case 16: return cs_mlp_split16_launch_h256(a, stream, waves16, terms16);
     }
     return cs_fail(CS_EUNSUPPORTED, "no kernel instance for hidden=" + std::to_string(a.net.nt * 16));
   }
@@ -208,6 +217,39 @@ void pack_layer3(std::vector<uint16_t>& s, const float* W, int k_real, int kt_co
 // term p of the 3-way split, per lane (m = lane&15, g = lane>>4), the 8 columns
 // k = 32s + 16(j>>2) + 4g + (j&3) of row tile_row(t, m) (-1 = padding): k-slot 8g + j of the matrix instruction
 // carries the feature that a lane of group g holds in register j&3 of tile 2s + (j>>2) of the previous layer.
+// fp16 of a float, round to nearest even (the compiler's conversion), as its 16 bits
+uint16_t f16_rne(float f) {
+  const _Float16 h = (_Float16)f;
+  uint16_t u;
+  std::memcpy(&u, &h, 2);
+  return u;
+}
+float f16_val(uint16_t u) {
+  _Float16 h;
+  std::memcpy(&h, &u, 2);
+  return (float)h;
+}
+// The same order with two fp16 terms per weight (w0 = fp16(w), w1 = fp16(w - w0)): the stream of the fp16-split
+// arithmetic.  Returns false when a weight does not fit fp16's range.
+template <class RowFn>
+bool pack_layer16h(std::vector<uint16_t>& s, const float* W, int k_real, int ks_count, int ntiles, RowFn tile_row) {
+  bool ok = true;
+  for (int ks = 0; ks < ks_count; ++ks)
+    for (int t = 0; t < ntiles; ++t)
+      for (int p = 0; p < 2; ++p)
+        for (int lane = 0; lane < 64; ++lane) {
+          const int m = lane & 15, g = lane >> 4;
+          const int n = tile_row(t, m);
+          for (int j = 0; j < 8; ++j) {
+            const int k = 32 * ks + 16 * (j >> 2) + 4 * g + (j & 3);
+            const float v = (n >= 0 && k < k_real) ? W[(size_t)n * k_real + k] : 0.0f;
+            if (!(std::fabs(v) <= 65504.0f)) ok = false;
+            const uint16_t t0 = f16_rne(v);
+            s.push_back(p == 0 ? t0 : f16_rne(v - f16_val(t0)));
+          }
+        }
+  return ok;
+}
 // terms = 1: the plain-bf16 stream, one fragment (the rounded weights) per tile.
 template <class RowFn>
 void pack_layer16(std::vector<uint16_t>& s, const float* W, int k_real, int ks_count, int ntiles, RowFn tile_row,
@@ -319,11 +361,18 @@ extern "C" int cs_mlp_create(const cs_mlp_desc* d, const float* W0, const float*
     for (int l = 0; l < 2; ++l) pack_layer16(s16b, Wblk + ((size_t)b * 2 + l) * H * H, H, NKT, NT, hid_row, 1);
   pack_layer16(s16b, Wf, H, NKT, nto, out_row, 1);
   s16b.resize(s16b.size() + ((size_t)2 * (NT > nto ? NT : nto) * 64 + 1024) * 8, 0);
+  std::vector<uint16_t> s16h;  // fp16-split arithmetic: two fp16 terms (left out when a weight exceeds fp16's range)
+  bool h_ok = pack_layer16h(s16h, W0, d->in_dim, nkt0, NT, hid_row);
+  for (int b = 0; b < nb; ++b)
+    for (int l = 0; l < 2; ++l) h_ok = pack_layer16h(s16h, Wblk + ((size_t)b * 2 + l) * H * H, H, NKT, NT, hid_row) && h_ok;
+  h_ok = pack_layer16h(s16h, Wf, H, NKT, nto, out_row) && h_ok;
+  s16h.resize(s16h.size() + ((size_t)2 * (NT > nto ? NT : nto) * 2 * 64 + 1024) * 8, 0);
 
   cs_mlp* m = new cs_mlp();
   m->desc = *d;
   m->d_w16 = nullptr;
   m->d_w16b = nullptr;
+  m->d_w16h = nullptr;
   m->d_w = nullptr;
   m->d_b = nullptr;
   m->d_w3 = nullptr;
@@ -342,9 +391,12 @@ extern "C" int cs_mlp_create(const cs_mlp_desc* d, const float* W0, const float*
   if (e == hipSuccess) e = hipMemcpy(m->d_w16, s16.data(), s16.size() * sizeof(uint16_t), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMalloc(&m->d_w16b, s16b.size() * sizeof(uint16_t));
   if (e == hipSuccess) e = hipMemcpy(m->d_w16b, s16b.data(), s16b.size() * sizeof(uint16_t), hipMemcpyHostToDevice);
+  if (e == hipSuccess && h_ok) e = hipMalloc(&m->d_w16h, s16h.size() * sizeof(uint16_t));
+  if (e == hipSuccess && h_ok) e = hipMemcpy(m->d_w16h, s16h.data(), s16h.size() * sizeof(uint16_t), hipMemcpyHostToDevice);
   if (e != hipSuccess) {
     if (m->d_w16) (void)hipFree(m->d_w16);
     if (m->d_w16b) (void)hipFree(m->d_w16b);
+    if (m->d_w16h) (void)hipFree(m->d_w16h);
     if (m->d_w) (void)hipFree(m->d_w);
     if (m->d_b) (void)hipFree(m->d_b);
     if (m->d_w3) (void)hipFree(m->d_w3);
@@ -371,6 +423,7 @@ extern "C" int cs_mlp_create(const cs_mlp_desc* d, const float* W0, const float*
   m->dev.bias_stride3 = bst3;
   m->dev.wstream16 = (const f32x4*)m->d_w16;
   m->dev.wstream16b = (const f32x4*)m->d_w16b;
+  m->dev.wstream16h = (const f32x4*)m->d_w16h;
   m->dev.arith = -1;
   *out = m;
   return CS_OK;
@@ -385,6 +438,7 @@ extern "C" int cs_mlp_destroy(cs_mlp_t* m) {
   if (m->d_b3) (void)hipFree(m->d_b3);
   if (m->d_w16) (void)hipFree(m->d_w16);
   if (m->d_w16b) (void)hipFree(m->d_w16b);
+  if (m->d_w16h) (void)hipFree(m->d_w16h);
   delete m;
   return CS_OK;
 }

@@ -535,10 +535,10 @@ def main():
     try:
         with open(os.path.join(ROOT, "roofline.json")) as f:
             out["measured_peaks"] = json.load(f)   # what a box of this kind sustains (tools/micro/peaks.hip), for context
-        on_data = out["measured_peaks"].get("mfma_on_data", {}).get("random_operands_tflops")
+        on_data = out["measured_peaks"].get("mfma_on_data", {}).get("f16_random_operands_tflops" if arith == "f16x2" else "random_operands_tflops")
         if split and on_data:
             # context only (`frac` stays priced on the nominal peak): what the matrix pipes alone sustain on random
-            # bf16 operands (tools/micro/mfma_data.hip), as algorithmic TFLOP/s of this arithmetic's product count
+            # operands of its instruction (tools/micro/mfma_data.hip), as algorithmic TFLOP/s of this arithmetic's product count
             roofline["matrix_pipes_on_data_tflops"] = on_data / nprod
             roofline["frac_of_matrix_pipes_on_data"] = roofline["achieved"] / (on_data / nprod)
     except (OSError, ValueError):

@@ -12,6 +12,7 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 #define CHECK(x)                                                                   \
@@ -28,8 +29,13 @@ __device__ __forceinline__ unsigned mix(unsigned x) {
 __device__ __forceinline__ unsigned rand_pair(unsigned h) {
   return (h & 0x807f807fU) | 0x3f803f80U;
 }
+// the same for fp16 (sign, exponent 15, 10 random mantissa bits)
+__device__ __forceinline__ unsigned rand_pair_f16(unsigned h) {
+  return (h & 0x83ff83ffU) | 0x3c003c00U;
+}
 
-template <bool RANDOM>
+// F16: v_mfma_f32_16x16x32_f16 instead of the bf16 form
+template <bool RANDOM, bool F16>
 __global__ void __launch_bounds__(256) mfma_stream(float* out, int iters, unsigned seed) {
   f32x4 acc[8];
 #pragma unroll
@@ -40,36 +46,38 @@ __global__ void __launch_bounds__(256) mfma_stream(float* out, int iters, unsign
   for (int k = 0; k < 8; ++k)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      a[k][r] = RANDOM ? rand_pair(mix(id + 8 * k + r)) : 0x3f803f80U;
-      b[k][r] = RANDOM ? rand_pair(mix(id + 32 + 8 * k + r)) : 0x3f803f80U;
+      a[k][r] = RANDOM ? (F16 ? rand_pair_f16(mix(id + 8 * k + r)) : rand_pair(mix(id + 8 * k + r))) : (F16 ? 0x3c003c00U : 0x3f803f80U);
+      b[k][r] = RANDOM ? (F16 ? rand_pair_f16(mix(id + 32 + 8 * k + r)) : rand_pair(mix(id + 32 + 8 * k + r))) : (F16 ? 0x3c003c00U : 0x3f803f80U);
     }
   for (int it = 0; it < iters; ++it)
 #pragma unroll
     for (int k = 0; k < 8; ++k)
 #pragma unroll
       for (int i = 0; i < 8; ++i)
-        acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[(k + i) & 7]),
-                                                         __builtin_bit_cast(bf16x8, b[k]), acc[i], 0, 0, 0);
+        acc[i] = F16 ? __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a[(k + i) & 7]),
+                                                              __builtin_bit_cast(f16x8, b[k]), acc[i], 0, 0, 0)
+                     : __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[(k + i) & 7]),
+                                                               __builtin_bit_cast(bf16x8, b[k]), acc[i], 0, 0, 0);
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
   if (s == 12345.678f) out[threadIdx.x] = s;  // keeps the accumulators live
 }
 
-template <bool RANDOM>
+template <bool RANDOM, bool F16>
 static double sustained_tflops(float* out, int blocks) {
   const int iters = 2000;  // 2000 * 64 instructions * 16 cycles: about 1 ms per launch
   const double flop = (double)blocks * 4 * iters * 64 * 16384.0;
   auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   double t0 = now();
   while (now() - t0 < 0.5) {  // settle
-    for (int i = 0; i < 20; ++i) hipLaunchKernelGGL(mfma_stream<RANDOM>, dim3(blocks), dim3(256), 0, 0, out, iters, 1u);
+    for (int i = 0; i < 20; ++i) hipLaunchKernelGGL((mfma_stream<RANDOM, F16>), dim3(blocks), dim3(256), 0, 0, out, iters, 1u);
     CHECK(hipDeviceSynchronize());
   }
   int n = 0;
   t0 = now();
   while (now() - t0 < 1.0) {
-    for (int i = 0; i < 20; ++i) hipLaunchKernelGGL(mfma_stream<RANDOM>, dim3(blocks), dim3(256), 0, 0, out, iters, 1u);
+    for (int i = 0; i < 20; ++i) hipLaunchKernelGGL((mfma_stream<RANDOM, F16>), dim3(blocks), dim3(256), 0, 0, out, iters, 1u);
     CHECK(hipDeviceSynchronize());
     n += 20;
   }
@@ -81,11 +89,14 @@ int main() {
   CHECK(hipGetDeviceProperties(&p, 0));
   const int cus = p.multiProcessorCount;
   float* out; CHECK(hipMalloc(&out, 4096));
-  const double c = sustained_tflops<false>(out, 2 * cus);
-  const double r = sustained_tflops<true>(out, 2 * cus);
-  const double c2 = sustained_tflops<false>(out, 2 * cus);
+  const double c = sustained_tflops<false, false>(out, 2 * cus);
+  const double r = sustained_tflops<true, false>(out, 2 * cus);
+  const double c2 = sustained_tflops<false, false>(out, 2 * cus);
+  const double hc = sustained_tflops<false, true>(out, 2 * cus);
+  const double hr = sustained_tflops<true, true>(out, 2 * cus);
   printf("{\"device\": \"%s\", \"compute_units\": %d, \"instruction\": \"v_mfma_f32_16x16x32_bf16\", \"waves_per_simd\": 2, "
-         "\"constant_operands_tflops\": %.1f, \"random_operands_tflops\": %.1f, \"constant_operands_again_tflops\": %.1f}\n",
-         p.gcnArchName, cus, c, r, c2);
+         "\"constant_operands_tflops\": %.1f, \"random_operands_tflops\": %.1f, \"constant_operands_again_tflops\": %.1f, "
+         "\"f16_constant_operands_tflops\": %.1f, \"f16_random_operands_tflops\": %.1f}\n",
+         p.gcnArchName, cus, c, r, c2, hc, hr);
   return 0;
 }

@@ -83,7 +83,7 @@ def test_acmwg_full_size_invariants(model):
     assert t == T - 1
 
 
-@pytest.mark.parametrize("arith", ["bf16x3", "f32"])
+@pytest.mark.parametrize("arith", ["bf16x3", "f16x2", "f32"])
 def test_repeated_full_size_launches_are_bit_identical(model, arith):
     """The same encoder / decoder launches on the same inputs, over and over: any difference is a race or a
     missed hardware hazard inside a kernel.  (Regression: the epilogue of the fused MLP kernel once read the

@@ -81,3 +81,39 @@ def test_fp16_split_fails_loudly_outside_its_range():
         big(x.cuda())
     big.packed().set_arith(None)
     assert torch.isfinite(big(torch.randn(8, 43).cuda())).all()
+
+
+@pytest.mark.parametrize("case", ["wide_inputs", "wide_weights", "small_everything"])
+def test_fp16_split_dynamic_range_within_a_row(case):
+    """Operands of very different sizes inside one row / one weight matrix: the fp16 split keeps the low-order term of a
+    small operand to 2^-24 absolute only, which matters next to nothing when the sum is dominated by the large ones
+    (the error is measured against the largest output, as for the other arithmetics) -- and shows when everything is
+    small (third case: the float32 kernels keep 1e-6, the fp16 split is allowed 1e-4 there)."""
+    from oracle import cs_oracle as O
+    from vae_conditional_sampling_amd.models import ResidualFCNetwork
+    g = torch.Generator().manual_seed(7)
+    w = O.make_resfc_weights(43, 64, 2, 256, seed=11)
+    x = torch.randn(2048, 43, generator=g)
+    if case == "wide_inputs":
+        x = x * torch.pow(10.0, torch.rand(43, generator=g) * 6 - 4)          # features scaled by 1e-4 ... 1e2
+    elif case == "wide_weights":
+        s = torch.pow(10.0, torch.rand(256, generator=g) * 4 - 3)             # hidden units scaled by 1e-3 ... 10,
+        w["W0"] = w["W0"] * s[:, None]                                        # undone by the next layer's columns
+        w["b0"] = w["b0"] * s
+        W1, b1, W2, b2 = w["blocks"][0]
+        w["blocks"][0] = (W1 / s[None, :], b1, W2, b2)
+    else:
+        x = x * 1e-3
+        w["b0"] = w["b0"] * 1e-3
+        w["blocks"] = [(W1, b1 * 1e-3, W2, b2 * 1e-3) for W1, b1, W2, b2 in w["blocks"]]
+        w["bf"] = w["bf"] * 1e-3
+    net = ResidualFCNetwork(43, 64, 2, 256).load_weight_dict(w).cuda().eval()
+    y64 = O.resfc_forward(to64(w), x.double())
+    err = {}
+    for arith in ("f32", "bf16x3", "f16x2"):
+        net.packed().set_arith(arith)
+        err[arith] = float((net(x.cuda()).cpu().double() - y64).abs().max() / y64.abs().max())
+    net.packed().set_arith(None)
+    print(f"{case}: max error / max|y| vs float64: f16x2 {err['f16x2']:.2e}, bf16x3 {err['bf16x3']:.2e}, exact f32 {err['f32']:.2e}")
+    assert err["f32"] < 3e-6 and err["bf16x3"] < 3e-6
+    assert err["f16x2"] < (1e-4 if case == "small_everything" else 5e-6)

@@ -208,3 +208,19 @@ def test_sampler_runs_unobserved_stretches_in_one_call_with_identical_results(tm
                 assert np.array_equal(f1[n][k], f8[n][k]), f"{n}[{k}] differs"
     assert f1["imputations_0.npz"]["imputations"].shape == (3, 64, 4, 43)
     np.testing.assert_allclose(o1[0]["is_ess"], o8[0]["is_ess"], rtol=1e-6)
+
+
+def test_yaml_driver_selects_the_arithmetic_per_run(tmp_path):
+    """`mlp_arith: f16x2` in a configuration pins the arithmetic on the run's network handles (not process-wide)."""
+    from vae_conditional_sampling_amd import _lib, driver
+    prev = _lib.get_mlp_arith()
+    cfg = driver.load_config(os.path.join(ROOT, "configs/uci_miniboone/sampling_u50/lair_k4_dmis_gr_mult_1replenish.yaml"),
+                             ["data.synthetic_num_test=70", "data.num_first_datapoints_test=64", "data.batch_size=64",
+                              f"trainer.default_root_dir={tmp_path}", "test_class.init_args.num_iterations=4",
+                              "mlp_arith=f16x2"])
+    tester, outs = driver.run(cfg)
+    assert tester.model.var_latent_network.packed().get_arith() == "f16x2"
+    assert tester.model.generator_network.packed().get_arith() == "f16x2"
+    assert _lib.get_mlp_arith() == prev
+    f0 = np.load(os.path.join(tester.out_dir, "imputations_0.npz"))
+    assert np.isfinite(f0["imputations"]).all()

@@ -133,6 +133,11 @@ def run(cfg, *, device=None, rank=0, world_size=1, gather_device=None):
         ckpt = find_checkpoint(cfg["model_path"], cfg.get("load_best"))
         print("Model path:", ckpt)
         model.load_state_dict(load_state_dict_from_checkpoint(ckpt), strict=True)
+    if cfg.get("mlp_arith") is not None:
+        # arithmetic of the matrix kernels for this run's networks (bf16x3 default | f32 | f16x2 | bf16, see csvae.h):
+        # set on the handles, not process-wide
+        for net in (model.var_latent_network, model.generator_network):
+            net.packed().set_arith(str(cfg["mlp_arith"]))
     tester.set_model(model)
     tester.set_datamodule(datamodule)
     datamodule.set_model(model)

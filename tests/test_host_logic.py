@@ -364,3 +364,23 @@ def test_sharded_artifact_merge_passes_switched_off_entries_through(tmp_path):
     assert len(paths) == 3
     f = np.load(paths[2])
     assert f["latents"].shape == (0,) and f["imputations"].shape == (1, 1, 3, 2) and f["data_idx"].tolist() == [8]
+
+
+def test_weight_transform_accepts_the_reference_callable():
+    """The function-level entry points take ``weight_transform`` as the reference passes it: a callable called with
+    ``log_weights=`` that multiplies them by a number (its polynomial transform); other callables raise."""
+    import functools
+
+    from vae_conditional_sampling_amd.sampling.vae_imputation import _weight_alpha
+
+    def polynomial_transform(log_weights, iter, max_iter):        # the reference's transform, restated
+        alpha = min((iter + 10) / max_iter, 1)
+        return log_weights * alpha
+
+    assert _weight_alpha(None) is None and _weight_alpha(0.25) == 0.25
+    assert abs(_weight_alpha(functools.partial(polynomial_transform, iter=5, max_iter=60)) - 0.25) < 1e-7
+    assert _weight_alpha(functools.partial(polynomial_transform, iter=500, max_iter=60)) == 1.0
+    with pytest.raises(NotImplementedError):
+        _weight_alpha(lambda log_weights: log_weights - 1.0)
+    with pytest.raises(NotImplementedError):
+        _weight_alpha("poly")

@@ -26,6 +26,24 @@ def _check_common(miss_model, accept_reject_xm, data_channel_dim):
         raise NotImplementedError("data_channel_dim is not implemented")
 
 
+def _weight_alpha(weight_transform):
+    """The multiplier of a log-weight transform.  The reference passes a callable, called as
+    ``weight_transform(log_weights=...)`` (vae_imputation.py:643-644); the only transform it has multiplies the
+    log-weights by a number (``polynomial_transform``, test_step_vae_sampling.py:2059-2061), and that is what the
+    resampling kernel applies.  A callable is therefore probed on a few values and accepted when it is such a
+    multiplication; anything else raises.  ``None`` and plain numbers pass through."""
+    if weight_transform is None or isinstance(weight_transform, (int, float)):
+        return weight_transform
+    if callable(weight_transform):
+        probe = torch.tensor([0.0, 1.0, -2.0, 3.5, -700.0])
+        out = torch.as_tensor(weight_transform(log_weights=probe), dtype=torch.float32).reshape(-1)
+        alpha = float(out[1])
+        if out.numel() == probe.numel() and torch.allclose(out, probe * alpha, rtol=1e-6, atol=0.0):
+            return alpha
+        raise NotImplementedError("weight_transform: only multiplication of the log-weights by a number is built")
+    raise NotImplementedError("weight_transform must be None, a number or a callable")
+
+
 def importance_resampling_gibbs_iteration(model, X, M, num_imp_samples, *, glr_cluster_size=None,
                                           weighting='dmis', resampling_method='multinomial', resampling_scheme='gr',
                                           num_prior_replenish_proposals=0,
@@ -45,8 +63,9 @@ def importance_resampling_gibbs_iteration(model, X, M, num_imp_samples, *, glr_c
     norm_log_weights[B,I*K'], Z_imp[I,B,K',Zd], log_weights[I,B,K'], acceptance_x
     (, latents_resampled[B,K',Zd])``.
 
-    ``weight_transform`` may be ``None`` or a float alpha (log-weights are multiplied by it
-    before resampling: the 'poly' transform of the sampler class).  The tensors returned are
+    ``weight_transform`` may be ``None``, a float alpha, or -- as the reference passes it -- a callable
+    ``f(log_weights=...)`` that multiplies the log-weights by a number (the 'poly' transform of the sampler class):
+    the log-weights are multiplied by it before resampling.  The tensors returned are
     views of the model's workspace and are overwritten by the next call (clone to keep)."""
     _check_common(miss_model, accept_reject_xm, data_channel_dim)
     _lib.proposal_transform_args(var_proposal_temperature, var_proposal_anneal_type_to_prior)
@@ -56,8 +75,7 @@ def importance_resampling_gibbs_iteration(model, X, M, num_imp_samples, *, glr_c
         raise NotImplementedError()
     if resampling_method not in ("multinomial", "systematic"):
         raise NotImplementedError()
-    if weight_transform is not None and not isinstance(weight_transform, (int, float)):
-        raise NotImplementedError("weight_transform must be None or a scalar multiplier")
+    weight_transform = _weight_alpha(weight_transform)
     if weighting == "dmis_within_groups" or resampling_scheme == "glr":
         assert glr_cluster_size is not None and glr_cluster_size > 1
     B, K, D = X.shape
@@ -123,8 +141,7 @@ def standard_importance_resampling(model, X, M, num_imp_samples, *, glr_cluster_
         raise NotImplementedError()
     if resampling_method not in ("multinomial", "systematic"):
         raise NotImplementedError()
-    if weight_transform is not None and not isinstance(weight_transform, (int, float)):
-        raise NotImplementedError("weight_transform must be None or a scalar multiplier")
+    weight_transform = _weight_alpha(weight_transform)
     if resampling_scheme == "glr":
         assert glr_cluster_size is not None and glr_cluster_size > 1
     B, K, D = X.shape

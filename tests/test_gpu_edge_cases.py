@@ -87,3 +87,26 @@ def test_unsupported_shapes_fail_loudly():
     bufs = _lib.make_bufs(X=Xg, q=q)
     rc = L.cs_lair_encode(enc.handle, C.byref(cfg), C.byref(bufs), _lib.current_stream())
     assert rc == -1 and b"encoder shape" in L.cs_last_error()
+
+
+def test_function_level_calls_return_fresh_tensors():
+    """As in the reference, two calls of importance_resampling_gibbs_iteration return tensors that do not alias each
+    other (the workspace views are an opt-in of inplace=True)."""
+    import torch
+    from oracle import cs_oracle as O
+    from tests.helpers import make_model, seeded_inputs
+    from vae_conditional_sampling_amd import _lib
+    from vae_conditional_sampling_amd.sampling.vae_imputation import importance_resampling_gibbs_iteration
+    model = make_model(O.make_resfc_weights(9, 8, 1, 64, 1), O.make_resfc_weights(4, 18, 1, 64, 2), device="cuda:0")
+    X, M = seeded_inputs(16, 3, 9, 5)
+    a = importance_resampling_gibbs_iteration(model, X.cuda(), M.cuda(), 1, num_prior_replenish_proposals=1, rng=_lib.make_rng(3, 0, 0))
+    keep = [t.clone() for t in a if torch.is_tensor(t)]
+    b = importance_resampling_gibbs_iteration(model, X.cuda(), M.cuda(), 1, num_prior_replenish_proposals=1, rng=_lib.make_rng(3, 1, 0))
+    for t, k in zip([t for t in a if torch.is_tensor(t)], keep):
+        assert torch.equal(t, k)                         # the first call's results survived the second call
+    assert not torch.equal(a[7], b[7])
+    v = importance_resampling_gibbs_iteration(model, X.cuda(), M.cuda(), 1, num_prior_replenish_proposals=1, rng=_lib.make_rng(3, 0, 0),
+                                              inplace=True)
+    w = importance_resampling_gibbs_iteration(model, X.cuda(), M.cuda(), 1, num_prior_replenish_proposals=1, rng=_lib.make_rng(3, 1, 0),
+                                              inplace=True)
+    assert v[7].data_ptr() == w[7].data_ptr()            # views of one workspace

@@ -26,6 +26,13 @@ def _check_common(miss_model, accept_reject_xm, data_channel_dim):
         raise NotImplementedError("data_channel_dim is not implemented")
 
 
+def _fresh(out):
+    """The reference returns new tensors from every call; the kernels write into the model's per-shape workspace.
+    Without ``inplace=True`` (the sampler classes' fast path: views of the workspace, overwritten by the next call of
+    the same shape) the workspace tensors are therefore copied.  ``out[0]`` is already the caller's own tensor."""
+    return (out[0],) + tuple(t.clone() if torch.is_tensor(t) else t for t in out[1:])
+
+
 def _weight_alpha(weight_transform):
     """The multiplier of a log-weight transform.  The reference passes a callable, called as
     ``weight_transform(log_weights=...)`` (vae_imputation.py:643-644); the only transform it has multiplies the
@@ -65,8 +72,9 @@ def importance_resampling_gibbs_iteration(model, X, M, num_imp_samples, *, glr_c
 
     ``weight_transform`` may be ``None``, a float alpha, or -- as the reference passes it -- a callable
     ``f(log_weights=...)`` that multiplies the log-weights by a number (the 'poly' transform of the sampler class):
-    the log-weights are multiplied by it before resampling.  The tensors returned are
-    views of the model's workspace and are overwritten by the next call (clone to keep)."""
+    the log-weights are multiplied by it before resampling.  As in the reference every call returns new tensors;
+    with ``inplace=True`` (an extension: ``X`` is updated in place) the statistics, proposals and log-weights are views
+    of the model's workspace instead, overwritten by the next call of the same shape."""
     _check_common(miss_model, accept_reject_xm, data_channel_dim)
     _lib.proposal_transform_args(var_proposal_temperature, var_proposal_anneal_type_to_prior)
     if weighting not in ("dmis", "dmis_within_groups", "smis"):
@@ -122,7 +130,7 @@ def importance_resampling_gibbs_iteration(model, X, M, num_imp_samples, *, glr_c
     out = (X_new, ws.stats[0], ws.stats[1], ws.stats[2], ws.I * ws.Kp, ws.norm_log_w, ws.Z, ws.log_w, acceptance_x)
     if return_resampled_latents:
         out = out + (ws.latents_resampled,)
-    return out
+    return out if inplace else _fresh(out)
 
 
 def standard_importance_resampling(model, X, M, num_imp_samples, *, glr_cluster_size=None,
@@ -131,7 +139,8 @@ def standard_importance_resampling(model, X, M, num_imp_samples, *, glr_cluster_
                                    rng=None, draws=None, inplace=False):
     """Importance resampling with the prior as the proposal of every chain (vae_imputation.py:904-998).
     Returns the reference's 8-tuple ``X_new, ess, transformed_ess, perplexity, total_num_props,
-    norm_log_weights, Z_imp[I,B,K,Zd], log_weights[I,B,K]`` (views of the model's workspace).
+    norm_log_weights, Z_imp[I,B,K,Zd], log_weights[I,B,K]`` (new tensors; views of the model's workspace with
+    ``inplace=True``).
     With the uniform prior the injected 'eps_z' holds the samples of Uniform(0, 1 + 1e-8)."""
     if data_channel_dim is not None:
         raise NotImplementedError("data_channel_dim is not implemented")
@@ -153,7 +162,8 @@ def standard_importance_resampling(model, X, M, num_imp_samples, *, glr_cluster_
         raise NotImplementedError("prior proposals: uniform prior with a non-Beta posterior (or the reverse)")
     X_new = (X if inplace else X.clone()).contiguous()
     engine.lair_step(model, ws, X_new, engine.mask_u8(M), cfg, rng=rng, draws=draws, prior_proposals=True)
-    return (X_new, ws.stats[0], ws.stats[1], ws.stats[2], ws.I * ws.Kp, ws.norm_log_w, ws.Z, ws.log_w)
+    out = (X_new, ws.stats[0], ws.stats[1], ws.stats[2], ws.I * ws.Kp, ws.norm_log_w, ws.Z, ws.log_w)
+    return out if inplace else _fresh(out)
 
 
 def pseudo_gibbs_iteration(model, X, M, clip_values_min=None, clip_values_max=None, *, data_channel_dim=None,
@@ -179,4 +189,4 @@ def pseudo_gibbs_iteration(model, X, M, clip_values_min=None, clip_values_max=No
     _lib.check(L.cs_lair_decode(model.generator_network.packed().handle, C.byref(cfg), C.byref(bufs), C.byref(rng), st))
     engine.sample_impute(model, ws.gen, X_new, M8, K, eps=draws.get("eps_x"), chi2=draws.get("chi2_x"), rng=rng, stream_id=_lib.STREAM_X,
                          clip_min=clip_values_min, clip_max=clip_values_max, nonfinite_keep=True)
-    return X_new, ws.Z[0]
+    return (X_new, ws.Z[0]) if inplace else (X_new, ws.Z[0].clone())

@@ -434,13 +434,16 @@ int cs_rng_uniform64(const cs_rng* rng, uint32_t stream_id, int64_t rows, int32_
  *                    a relative rounding error of up to 2^-9; results follow a bfloat16-rounded evaluation of
  *                    the network (tests/test_gpu_bf16_arith.py), not the reference's float32 one.  Fused MLP
  *                    kernel only; layer-program networks keep CS_ARITH_BF16X3 under this setting.
- *   CS_ARITH_F16X2   experimental, opt-in: every float32 operand as two fp16 terms (11 + 11 significand bits),
- *                    three products per pair, float32 accumulation: half the matrix work of CS_ARITH_BF16X3.  The
- *                    neglected term is below 2^-22 |a||b|; against a float64 evaluation the error is within a small
- *                    factor of the float32 kernels' (tests/test_gpu_f16x2_arith.py) for operands of ordinary size.
- *                    fp16 has 5 exponent bits: activations beyond 65504 in magnitude are wrong (saturated, not
- *                    flagged), a network with such a weight is refused, and operands far below 1 lose relative
- *                    accuracy in their low-order term (kept to 2^-24 absolute).  Fused MLP kernel only.
+ *   CS_ARITH_F16X2   opt-in: every float32 operand as two fp16 terms (11 + 11 significand bits), three products
+ *                    per pair, float32 accumulation: half the matrix work of CS_ARITH_BF16X3 (1.5x its throughput).
+ *                    fp16's 5 exponent bits are dealt with by exact powers of two: every operand row is normalised
+ *                    (its largest magnitude into [1, 2)) and every layer's weights (largest into [2^14, 2^15)), the
+ *                    exponents are carried along and taken out at the end.  The neglected term is below 2^-22 |a||b|;
+ *                    against a float64 evaluation the error is that of the float32 kernels or lower
+ *                    (tests/test_gpu_f16x2_arith.py), for inputs and weights of any scale.  The limit: an operand
+ *                    below 2^-3 of its row's largest keeps fewer than 22 bits (11 below 2^-14 of it), which shows
+ *                    (a few 1e-6) only where the weights undo a spread of 1e4 inside a row.  A network with a
+ *                    non-finite weight is refused.  Fused MLP kernel only.
  * The setting is process-wide and applies to launches made after the call; the environment variable
  * CSVAE_MLP_ARITH (bf16x3 | f32 | bf16 | f16x2) gives the initial value.  It also selects the kernels of the matrix-core
  * convolution / linear layers of layer-program networks (cs_net_create). */

@@ -25,7 +25,8 @@ struct CsMlpDev {
   // bias table and output tile geometry are those of the exact-f32 kernel (bias, nto, tph)
   const f32x4* wstream16;
   const f32x4* wstream16b;  // the same order with one term, the weights rounded to bf16 (CS_ARITH_BF16)
-  const f32x4* wstream16h;  // the same order with two fp16 terms (CS_ARITH_F16X2); null when a weight exceeds fp16's range
+  const f32x4* wstream16h;  // the same order with two fp16 terms (CS_ARITH_F16X2); null when a weight is not finite
+  signed char wexp16h[36];  // per layer (first, block layers, output): the power of two its fp16 stream is scaled by
   int arith;             // CS_ARITH_* of this network, or -1: the process default (cs_set_mlp_arith)
 };
 

@@ -115,7 +115,7 @@ int cs_mlp_launch(const CsMlpArgs& a_in, hipStream_t stream) {
   if (arith == CS_ARITH_BF16) CS_REQUIRE(cs_split16_fits(a.net, waves16, 1), "network does not fit the LDS budget");
   if (arith == CS_ARITH_F16X2) {
     CS_REQUIRE(cs_split16_fits(a.net, waves16, 2), "network does not fit the LDS budget");
-    CS_REQUIRE(a.net.wstream16h != nullptr, "a weight of this network exceeds the range of fp16: no fp16-split arithmetic");
+    CS_REQUIRE(a.net.wstream16h != nullptr, "a weight of this network is not finite: no fp16-split arithmetic");
   }
   const int terms16 = arith == CS_ARITH_BF16 ? 1 : (arith == CS_ARITH_F16X2 ? 2 : 3);
   if (a.mode == CS_MLP_DEC && a.in == nullptr &&
@@ -229,11 +229,24 @@ float f16_val(uint16_t u) {
   std::memcpy(&h, &u, 2);
   return (float)h;
 }
-// The same order with two fp16 terms per weight (w0 = fp16(w), w1 = fp16(w - w0)): the stream of the fp16-split
-// arithmetic.  Returns false when a weight does not fit fp16's range.
+// The same order with two fp16 terms per weight (w0 = fp16(w'), w1 = fp16(w' - w0)), w' = w 2^kexp: the stream of
+// the fp16-split arithmetic.  kexp (returned through *kexp_out) is chosen per layer so that the largest weight lands in
+// [2^14, 2^15): the high terms use fp16's range and the low terms are normal numbers down to weights 2^-17 of the
+// largest; the kernel carries the exponent in its row scaling.  Returns false when a weight is not finite.
 template <class RowFn>
-bool pack_layer16h(std::vector<uint16_t>& s, const float* W, int k_real, int ks_count, int ntiles, RowFn tile_row) {
+bool pack_layer16h(std::vector<uint16_t>& s, const float* W, int n_real, int k_real, int ks_count, int ntiles, RowFn tile_row,
+                   signed char* kexp_out) {
   bool ok = true;
+  float mx = 0.0f;
+  for (size_t i = 0; i < (size_t)n_real * k_real; ++i) {
+    if (!std::isfinite(W[i])) ok = false;
+    mx = std::fmax(mx, std::fabs(W[i]));
+  }
+  int ex = 0;
+  if (mx > 0.0f && std::isfinite(mx)) (void)std::frexp(mx, &ex);  // mx = m 2^ex, m in [0.5, 1)
+  int kexp = mx > 0.0f ? 15 - ex : 0;                              // mx 2^kexp in [2^14, 2^15)
+  kexp = kexp < -100 ? -100 : (kexp > 100 ? 100 : kexp);
+  *kexp_out = (signed char)kexp;
   for (int ks = 0; ks < ks_count; ++ks)
     for (int t = 0; t < ntiles; ++t)
       for (int p = 0; p < 2; ++p)
@@ -242,8 +255,7 @@ bool pack_layer16h(std::vector<uint16_t>& s, const float* W, int k_real, int ks_
           const int n = tile_row(t, m);
           for (int j = 0; j < 8; ++j) {
             const int k = 32 * ks + 16 * (j >> 2) + 4 * g + (j & 3);
-            const float v = (n >= 0 && k < k_real) ? W[(size_t)n * k_real + k] : 0.0f;
-            if (!(std::fabs(v) <= 65504.0f)) ok = false;
+            const float v = (n >= 0 && k < k_real) ? std::ldexp(W[(size_t)n * k_real + k], kexp) : 0.0f;
             const uint16_t t0 = f16_rne(v);
             s.push_back(p == 0 ? t0 : f16_rne(v - f16_val(t0)));
           }
@@ -362,10 +374,12 @@ extern "C" int cs_mlp_create(const cs_mlp_desc* d, const float* W0, const float*
   pack_layer16(s16b, Wf, H, NKT, nto, out_row, 1);
   s16b.resize(s16b.size() + ((size_t)2 * (NT > nto ? NT : nto) * 64 + 1024) * 8, 0);
   std::vector<uint16_t> s16h;  // fp16-split arithmetic: two fp16 terms (left out when a weight exceeds fp16's range)
-  bool h_ok = pack_layer16h(s16h, W0, d->in_dim, nkt0, NT, hid_row);
+  signed char wexp[36] = {};
+  bool h_ok = pack_layer16h(s16h, W0, H, d->in_dim, nkt0, NT, hid_row, &wexp[0]);
   for (int b = 0; b < nb; ++b)
-    for (int l = 0; l < 2; ++l) h_ok = pack_layer16h(s16h, Wblk + ((size_t)b * 2 + l) * H * H, H, NKT, NT, hid_row) && h_ok;
-  h_ok = pack_layer16h(s16h, Wf, H, NKT, nto, out_row) && h_ok;
+    for (int l = 0; l < 2; ++l)
+      h_ok = pack_layer16h(s16h, Wblk + ((size_t)b * 2 + l) * H * H, H, H, NKT, NT, hid_row, &wexp[1 + 2 * b + l]) && h_ok;
+  h_ok = pack_layer16h(s16h, Wf, d->out_dim, H, NKT, nto, out_row, &wexp[2 * nb + 1]) && h_ok;
   s16h.resize(s16h.size() + ((size_t)2 * (NT > nto ? NT : nto) * 2 * 64 + 1024) * 8, 0);
 
   cs_mlp* m = new cs_mlp();
@@ -424,6 +438,7 @@ extern "C" int cs_mlp_create(const cs_mlp_desc* d, const float* W0, const float*
   m->dev.wstream16 = (const f32x4*)m->d_w16;
   m->dev.wstream16b = (const f32x4*)m->d_w16b;
   m->dev.wstream16h = (const f32x4*)m->d_w16h;
+  std::memcpy(m->dev.wexp16h, wexp, sizeof(wexp));
   m->dev.arith = -1;
   *out = m;
   return CS_OK;

@@ -130,3 +130,24 @@ def test_fp16_split_dynamic_range_within_a_row(case):
     print(f"{case}: max error / max|y| vs float64: f16x2 {err['f16x2']:.2e}, bf16x3 {err['bf16x3']:.2e}, exact f32 {err['f32']:.2e}")
     assert err["f32"] < 3e-6 and err["bf16x3"] < 3e-6
     assert err["f16x2"] < (8e-6 if case == "wide_weights" else 2e-6)
+
+
+def test_fp16_split_rows_and_layers_of_zeros():
+    """Rows that are exactly zero (and stay zero through layers whose biases are zero) carry no scale: the exponent
+    bookkeeping must not drift with them.  Deep net (8 blocks), zero input rows, zero biases in the first five layers."""
+    from oracle import cs_oracle as O
+    from vae_conditional_sampling_amd.models import ResidualFCNetwork
+    w = O.make_resfc_weights(21, 32, 8, 128, seed=2)
+    w["b0"] = torch.zeros_like(w["b0"])
+    w["blocks"] = [(W1, torch.zeros_like(b1) if i < 2 else b1, W2, torch.zeros_like(b2) if i < 2 else b2)
+                   for i, (W1, b1, W2, b2) in enumerate(w["blocks"])]
+    x = torch.randn(96, 21, generator=torch.Generator().manual_seed(3))
+    x[::3] = 0.0
+    net = ResidualFCNetwork(21, 32, 8, 128).load_weight_dict(w).cuda().eval()
+    y64 = O.resfc_forward(to64(w), x.double())
+    net.packed().set_arith("f16x2")
+    y = net(x.cuda()).cpu().double()
+    net.packed().set_arith(None)
+    assert torch.isfinite(y).all()
+    assert float((y - y64).abs().max() / y64.abs().max()) < 2e-6
+    assert float((y[::3] - y64[::3]).abs().max() / y64[::3].abs().max()) < 2e-6

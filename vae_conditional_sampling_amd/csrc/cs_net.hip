@@ -406,6 +406,16 @@ __device__ __forceinline__ unsigned conv_cvt_pk(float lo, float hi) {
 }
 #define CS_CONV_MFMA32(A_, B_, C_) \
   C_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8n, A_), __builtin_bit_cast(bf16x8n, B_), C_, 0, 0, 0)
+// -DCS_CONV_STAMPS (debug builds only, see tools/conv_stamps.py): the 100 MHz clock of wave 0 of every workgroup at the
+// phase boundaries of the halo kernel (entry, window and first weight tile staged, last matrix instruction issued,
+// stores issued), plus the shader clock over the loop
+#ifdef CS_CONV_STAMPS
+__device__ unsigned long long cs_conv_stamps[8 * 8192];
+#define CS_CONV_STAMP(i_, v_)                                                                     \
+  if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && blockIdx.x < 8192) cs_conv_stamps[blockIdx.x * 8 + (i_)] = (v_)
+#else
+#define CS_CONV_STAMP(i_, v_)
+#endif
 constexpr int CS_HALO_NPMAX = 10;  // staging passes: (32*PT*NW + 2*64) rows * 8 threads / (64*NW) threads
 template <int CT, int PT, int NW, bool PHASE>
 __global__ void __launch_bounds__(64 * NW) cs_conv3x3_halo_split_kernel(const CsConvArgs a, int NR, int NP) {
@@ -414,6 +424,7 @@ __global__ void __launch_bounds__(64 * NW) cs_conv3x3_halo_split_kernel(const Cs
   // (pa + dh, pb + dw) of a same-size 3x3 convolution reads, so the window, the tap masks and the fragment addresses
   // are those of the 3x3 case; the output pixel is (2i + pa, 2j + pb) of the upsampled grid.
   constexpr int NT = PHASE ? 4 : 9;
+  CS_CONV_STAMP(0, __builtin_amdgcn_s_memrealtime());
   const int pa = PHASE ? (int)(blockIdx.z >> 1) : 0, pb = PHASE ? (int)(blockIdx.z & 1) : 0;
   constexpr int NTHR = 64 * NW, RPP = NTHR / 8;  // threads; window rows staged per pass
   constexpr int PX = 32 * PT;                    // pixels per wavefront
@@ -436,29 +447,7 @@ __global__ void __launch_bounds__(64 * NW) cs_conv3x3_halo_split_kernel(const Cs
 
   unsigned tapmask[PT];
   int row0[PT];
-#pragma unroll
-  for (int p = 0; p < PT; ++p) {
-    row0[p] = wave * PX + p * 32 + l31;
-    const int64_t gp = p0 + row0[p];
-    const int hw = H * W;
-    const int64_t g = gp < a.npix ? gp : 0;
-    const int rem = (int)(g % hw);
-    const int oh = rem / W, ow = rem - oh * W;
-    tapmask[p] = 0;
-#pragma unroll
-    for (int t = 0; t < 9; ++t) {
-      const int ih = oh + t / 3 - 1, iw = ow + t % 3 - 1;
-      if (gp < a.npix && ih >= 0 && ih < H && iw >= 0 && iw < W) tapmask[p] |= 1u << t;
-    }
-  }
-
   f32x16 acc[PT][CT];
-#pragma unroll
-  for (int p = 0; p < PT; ++p)
-#pragma unroll
-    for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[p][ct][r] = 0.0f;
 
   f32x4 rh[CS_HALO_NPMAX];
   auto fetch_halo = [&](int cc) {
@@ -510,13 +499,40 @@ __global__ void __launch_bounds__(64 * NW) cs_conv3x3_halo_split_kernel(const Cs
     return ((tapmask[p] >> (kh * 3 + kw)) & 1u) ? o : zero_off + (unsigned)(h << 4);
   };
 
+  // the window and the first weight tile are requested first: the tap masks are computed under their latency
   fetch_halo(0);
 #pragma unroll
   for (int r = 0; r < NPC; ++r) dma_copy(0 * ncc + 0, 0, r);
   if (tid < 16) *(lds_u32x4n*)(s_halo + zero_off + tid * 16) = u32x4n{0u, 0u, 0u, 0u};
+  // position of the block's first pixel inside its image: one 64-bit division per workgroup (uniform), 32-bit
+  // arithmetic per lane (a block spans fewer than 2^10 pixels)
+  const int hw = H * W;
+  const int rem0 = (int)cs_scalar_u32((unsigned)(p0 % hw));
+#pragma unroll
+  for (int p = 0; p < PT; ++p) {
+    row0[p] = wave * PX + p * 32 + l31;
+    const int64_t gp = p0 + row0[p];
+    const int rem = (int)((unsigned)(rem0 + row0[p]) % (unsigned)hw);
+    const int oh = rem / W, ow = rem - oh * W;
+    tapmask[p] = 0;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int ih = oh + t / 3 - 1, iw = ow + t % 3 - 1;
+      if (gp < a.npix && ih >= 0 && ih < H && iw >= 0 && iw < W) tapmask[p] |= 1u << t;
+    }
+  }
+
+#pragma unroll
+  for (int p = 0; p < PT; ++p)
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[p][ct][r] = 0.0f;
   stash_halo();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  CS_CONV_STAMP(1, __builtin_amdgcn_s_memrealtime());
+  CS_CONV_STAMP(4, __builtin_amdgcn_s_memtime());
 
   u32x4n wr[2][3];
   u32x4n br[2][PT][3];
@@ -614,6 +630,8 @@ __global__ void __launch_bounds__(64 * NW) cs_conv3x3_halo_split_kernel(const Cs
     }
   }
   cs_mfma_drain();
+  CS_CONV_STAMP(2, __builtin_amdgcn_s_memrealtime());
+  CS_CONV_STAMP(5, __builtin_amdgcn_s_memtime());
   if ((a.cout & 31) == 0 && !a.out_nchw) {
     __syncthreads();  // the ring and the window are dead: the LDS becomes per-wave transposition space
     conv_store_rows<CT, PT, PHASE>(a, acc, (conv_lds_byte*)s_raw + wave * (PX * (CT * 128 + 16)), p0 + wave * PX,
@@ -622,6 +640,7 @@ __global__ void __launch_bounds__(64 * NW) cs_conv3x3_halo_split_kernel(const Cs
 #pragma unroll
     for (int p = 0; p < PT; ++p) conv_store<CT>(a, acc[p], p0 + row0[p], blockIdx.y * (CT * 32), h);
   }
+  CS_CONV_STAMP(3, __builtin_amdgcn_s_memrealtime());
 }
 // 32 -> 32 channel same-size 3x3 convolutions (the 14x14 stages of the MNIST-GMM nets): 30 algorithmic GFLOP against
 // 0.4-0.6 GB of activations per layer at 8192 images, bound by HBM, and a block of the kernel above is all prologue and
@@ -2033,3 +2052,9 @@ int cs_prog_launch(const CsMlpArgs& a, hipStream_t stream) {
   }
   return CS_OK;
 }
+
+#ifdef CS_CONV_STAMPS
+extern "C" int cs_debug_conv_stamps(unsigned long long* out, int n) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(cs_conv_stamps), (size_t)n * sizeof(unsigned long long));
+}
+#endif

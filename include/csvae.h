@@ -464,6 +464,10 @@ int cs_debug_set_trace(long long* buf);
  * layer-program networks, which decides how many rows one pass processes; 0 restores the default
  * (6 GiB). */
 int cs_debug_set_workspace_budget(int64_t bytes);
+/* Test hook (no counterpart in the reference): cs_lair_resample_impute handles proposal sets of up to 64 per
+ * example (I*K') in one launch, one wavefront per group of examples, and larger sets in three launches; with
+ * on = 1 every size takes the three-launch path.  Returns the previous setting. */
+int cs_debug_force_large_resample(int on);
 
 #ifdef __cplusplus
 }

@@ -544,6 +544,19 @@ def main():
                nkpc=4, cluster=5, R=5, plain_mwg=True)
     case_pseudo_gibbs(ns, "pseudo_gibbs_clip", B=4, K=3, D=7, Zd=3, H=64, seed=969, T=6, clip=True)
     case_pseudo_gibbs(ns, "pseudo_gibbs_noclip", B=3, K=2, D=6, Zd=3, H=64, seed=979, T=5, clip=False)
+    # proposal sets of more than 64 per example (configs/mnist_gmm/samples/vae_convresnet3_k100_irwg_i1_dmisg_glr5_mult.yaml:
+    # K=100 in clusters of 5 with grouped weights; the stage after the networks is the same for any network family)
+    case_lair(ns, "lair_k100_glr5_dmisg", B=3, K=100, R=0, I=1, D=11, Zd=5, H=64, nb_enc=1, nb_dec=1, seed=616,
+              scheme="glr", weighting="dmis_within_groups", cluster=5)
+    case_lair(ns, "lair_k96_r4_gr_dmis_lat", B=3, K=96, R=4, I=1, D=9, Zd=4, H=64, nb_enc=1, nb_dec=1, seed=626,
+              resampled_latents=True)
+    case_lair(ns, "lair_k40_i3_gr_syst", B=3, K=40, R=2, I=3, D=9, Zd=4, H=64, nb_enc=1, nb_dec=1, seed=636,
+              method="systematic")
+    case_lair(ns, "lair_k30_i4_lr_smis", B=3, K=30, R=0, I=4, D=9, Zd=4, H=64, nb_enc=1, nb_dec=1, seed=646,
+              scheme="lr", weighting="smis")
+    case_lair(ns, "lair_k24_i5_ir", B=3, K=24, R=0, I=5, D=8, Zd=4, H=64, nb_enc=1, nb_dec=1, seed=656, scheme="ir")
+    case_lair(ns, "lair_k120_glr10_dmis", B=2, K=120, R=0, I=1, D=8, Zd=4, H=64, nb_enc=1, nb_dec=1, seed=666,
+              scheme="glr", weighting="dmis", cluster=10)
     case_lair_sampler(ns, "lair_sampler_final", B=4, K=3, R=1, D=8, Zd=4, H=64, seed=111, T=5)
     case_lair_sampler(ns, "lair_sampler_final_n5", B=3, K=4, R=1, D=8, Zd=4, H=64, seed=222, T=4, n_final=5)
     case_lair_sampler(ns, "lair_sampler_history_gr", B=4, K=3, R=1, D=8, Zd=4, H=64, seed=333, T=7, final=False,

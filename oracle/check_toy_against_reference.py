@@ -40,7 +40,7 @@ def ref_vae(ns, enc, dec):
                       lr_generator=1e-3, lr_latent=1e-3, use_uniform_prior=True).eval()
 
 
-def case_toy_lair(ns, name, *, H, nb, K, R, I, Zd, seed, iters=2):
+def case_toy_lair(ns, name, *, H, nb, K, R, I, Zd, seed, iters=2, scheme="gr", weighting="dmis", cluster=None):
     D = 2
     enc = O.make_resfc_weights(D, 2 * Zd, nb, H, seed)
     dec = O.make_resfc_weights(Zd, 2 * D, nb, H, seed + 1)
@@ -53,20 +53,22 @@ def case_toy_lair(ns, name, *, H, nb, K, R, I, Zd, seed, iters=2):
     M = M.unsqueeze(1)
     # weights are not stored: tests regenerate them with O.make_resfc_weights from (seed, nb)
     fx = dict(X0=X.numpy(), M=M.numpy(), cfg=np.array([B, K, R, I, D, Zd, H, iters], dtype=np.int64),
-              wseed=np.array([seed, nb], dtype=np.int64))
+              wseed=np.array([seed, nb], dtype=np.int64), scheme=np.array(scheme), weighting=np.array(weighting),
+              cluster=np.int64(cluster or 0))
     tape = DrawTape(seed + 3)
     Xr = X.clone()
     for t in range(iters):
         n0 = len(tape.entries)
         with torch.no_grad(), tape.recording():
             ret = ns.vae_imputation.importance_resampling_gibbs_iteration(
-                vae, Xr, M, I, glr_cluster_size=None, weighting="dmis", resampling_method="multinomial",
-                resampling_scheme="gr", num_prior_replenish_proposals=R)
+                vae, Xr, M, I, glr_cluster_size=cluster, weighting=weighting, resampling_method="multinomial",
+                resampling_scheme=scheme, num_prior_replenish_proposals=R)
         ent = tape.entries[n0:]
         assert [k for k, _ in ent] == ["beta", "multinomial", "normal"], [k for k, _ in ent]
         draws = {"eps_z": torch.from_numpy(ent[0][1]), "u_res": torch.from_numpy(ent[1][1]), "eps_x": torch.from_numpy(ent[2][1])}
         o = O.lair_iteration(enc, dec, Xr, M, draws, num_imp_samples=I, num_prior_replenish_proposals=R,
-                             latent_dist="beta", prior="uniform")
+                             latent_dist="beta", prior="uniform", weighting=weighting, resampling_scheme=scheme,
+                             glr_cluster_size=cluster)
         assert torch.equal(o["Z_imp"], ret[6])
         assert torch.equal(o["log_weights"], ret[7]), float((o["log_weights"] - ret[7]).abs().max())
         assert torch.equal(o["X_new"], ret[0])
@@ -140,6 +142,12 @@ def main():
     case_toy_lair(ns, "toy_lair_beta_uniform_h64", H=64, nb=2, K=4, R=1, I=1, Zd=1, seed=500)
     case_toy_lair(ns, "toy_lair_beta_uniform_zd3_i2", H=64, nb=1, K=3, R=2, I=2, Zd=3, seed=510)
     case_toy_lair(ns, "toy_lair_beta_uniform_h512", H=512, nb=4, K=4, R=1, I=1, Zd=1, seed=520, iters=1)
+    # the toy configurations with hundreds of chains (configs/toy_grid2dmog4/sampling/vae_comptrain/irwg_k500_dmis_gr_mult_it10.yaml,
+    # irwg_k500_dmis_glr5_mult_it10.yaml, irwg_k500_smis_glr5_mult_it100.yaml)
+    case_toy_lair(ns, "toy_lair_k500_dmis_gr", H=64, nb=1, K=500, R=0, I=1, Zd=1, seed=540, iters=2)
+    case_toy_lair(ns, "toy_lair_k500_dmis_glr5", H=64, nb=1, K=500, R=0, I=1, Zd=1, seed=550, iters=1, scheme="glr", cluster=5)
+    case_toy_lair(ns, "toy_lair_k500_smis_glr5", H=64, nb=1, K=500, R=0, I=1, Zd=1, seed=560, iters=1, scheme="glr",
+                  weighting="smis", cluster=5)
     case_toy_sampler(ns, "toy_sampler_beta_uniform", H=64, nb=1, K=4, R=1, seed=530, T=5)
 
 

@@ -43,12 +43,12 @@ def test_argument_validation_without_gpu():
     assert rc == -1 and b"hidden" in L.cs_last_error()
     rc = L.cs_mlp_forward(None, None, 0, None, None)
     assert rc == -1
-    cfg = _lib.cs_lair_cfg(1, 60, 10, 1, 4, 2, 1, 1, 0, 0, 0, 0, 1.0)  # I*(K+R) = 70 > 64
+    cfg = _lib.cs_lair_cfg(1, 60, 10, 1, 4, 2, 1, 1, 0, 1, 0, 9, 1.0)  # glr: clusters of 9 do not divide K+R = 70
     b = _lib.cs_lair_bufs()
     for f, _ in b._fields_:
         setattr(b, f, 8)  # non-null placeholders; validation fails before any dereference
     rc = L.cs_lair_resample_impute(C.byref(cfg), C.byref(b), None, None)
-    assert rc == -1 and b"<= 64" in L.cs_last_error()
+    assert rc == -1 and b"glr needs cluster_size" in L.cs_last_error()
 
 
 def test_product_path_refuses_cpu_tensors():

@@ -64,8 +64,27 @@ def test_mlp_with_block_normalisation_matches_reference_golden(name):
     assert ("blocks.0.layer_norm.weight" if kind == "layer" else "blocks.0.batch_norm.running_var") in sd
 
 
+@pytest.fixture
+def large_resample_path():
+    """Every proposal-set size through the three-launch path that sets of more than 64 proposals take."""
+    from vae_conditional_sampling_amd import _lib
+    prev = _lib.lib().cs_debug_force_large_resample(1)
+    yield
+    _lib.lib().cs_debug_force_large_resample(prev)
+
+
 @pytest.mark.parametrize("name", LAIR_CASES)
 def test_lair_iteration_matches_reference_golden(name):
+    run_lair_case(name)
+
+
+@pytest.mark.parametrize("name", LAIR_CASES)
+def test_lair_iteration_through_the_large_set_path_matches_reference_golden(name, large_resample_path):
+    """The reference's small fixtures through the kernels of the large proposal sets: same bar."""
+    run_lair_case(name)
+
+
+def run_lair_case(name):
     from vae_conditional_sampling_amd.sampling.vae_imputation import importance_resampling_gibbs_iteration
     fx = load_golden(name)
     B, K, R, I, D, Zd, H, cluster, iters = [int(v) for v in fx["cfg"]]

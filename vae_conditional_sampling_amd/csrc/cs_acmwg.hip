@@ -467,22 +467,23 @@ extern "C" int cs_acmwg_step(const cs_mlp_t* enc, const cs_mlp_t* dec, const cs_
 struct CsHistConcatArgs {
   const float* X; const float* ring; const uint8_t* ring8; float* Xc; const int64_t* chain_of_example; CsPhilox rng;
   int64_t B; int K, D, H; int use_chain_of_proposal;
+  int k_lo, k_cnt, h0;   // this launch writes chains [k_lo, k_lo + k_cnt) of Xc; slots / chain_of_proposal hold proposals h0..
   int slots[64]; int chain_of_proposal[64];
 };
 
 __global__ void __launch_bounds__(256) cs_history_concat_kernel(const CsHistConcatArgs a) {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int KH = a.K + a.H;
-  if (t >= a.B * KH * a.D) return;
+  if (t >= a.B * a.k_cnt * a.D) return;
   const int d = (int)(t % a.D);
   const int64_t bk = t / a.D;
-  const int k = (int)(bk % KH);
-  const int64_t b = bk / KH;
+  const int k = a.k_lo + (int)(bk % a.k_cnt);
+  const int64_t b = bk / a.k_cnt;
   float v;
   if (k < a.K) {
     v = a.X[(b * a.K + k) * a.D + d];
   } else {
-    const int h = k - a.K;
+    const int h = k - a.K - a.h0;
     int chain;
     if (a.use_chain_of_proposal) {
       chain = a.chain_of_proposal[h];
@@ -496,26 +497,36 @@ __global__ void __launch_bounds__(256) cs_history_concat_kernel(const CsHistConc
     const int64_t e = (((int64_t)a.slots[h] * a.B + b) * a.K + chain) * a.D + d;
     v = a.ring8 ? (float)a.ring8[e] : a.ring[e];
   }
-  a.Xc[t] = v;
+  a.Xc[(b * KH + k) * a.D + d] = v;
 }
 
 static int history_concat(const float* X, const float* ring, const uint8_t* ring8, int64_t B, int32_t K, int32_t D, int32_t H,
                           const int32_t* slots, const int32_t* chain_of_proposal, const int64_t* chain_of_example,
                           const cs_rng* rng, float* Xc, void* stream) {
   CS_REQUIRE(X && (ring || ring8) && Xc && slots && B >= 0 && K >= 1 && D >= 1, "bad argument");
-  CS_REQUIRE(H >= 1 && H <= 64, "number of historical proposals must be in [1,64]");
+  CS_REQUIRE(H >= 1, "number of historical proposals must be positive");
+  for (int h = 0; h < H; ++h)
+    CS_REQUIRE(slots[h] >= 0 && (!chain_of_proposal || (chain_of_proposal[h] >= 0 && chain_of_proposal[h] < K)),
+               "bad slot / chain index");
   if (B == 0) return CS_OK;
   CsHistConcatArgs a;
   a.X = X; a.ring = ring; a.ring8 = ring8; a.Xc = Xc; a.chain_of_example = chain_of_example; a.rng = cs_make_philox(rng);
   a.B = B; a.K = K; a.D = D; a.H = H; a.use_chain_of_proposal = chain_of_proposal != nullptr;
-  for (int h = 0; h < 64; ++h) {
-    a.slots[h] = h < H ? slots[h] : 0;
-    a.chain_of_proposal[h] = (h < H && chain_of_proposal) ? chain_of_proposal[h] : 0;
-    CS_REQUIRE(a.slots[h] >= 0 && a.chain_of_proposal[h] >= 0 && a.chain_of_proposal[h] < K, "bad slot / chain index");
+  // the slot / chain tables travel in the kernel arguments, 64 historical proposals per launch; the first launch
+  // also copies the K current chains
+  for (int h0 = 0; h0 < H; h0 += 64) {
+    const int hc = (H - h0) < 64 ? (H - h0) : 64;
+    a.h0 = h0;
+    a.k_lo = h0 == 0 ? 0 : K + h0;
+    a.k_cnt = h0 == 0 ? K + hc : hc;
+    for (int h = 0; h < 64; ++h) {
+      a.slots[h] = h < hc ? slots[h0 + h] : 0;
+      a.chain_of_proposal[h] = (h < hc && chain_of_proposal) ? chain_of_proposal[h0 + h] : 0;
+    }
+    const int64_t n = B * a.k_cnt * D;
+    hipLaunchKernelGGL(cs_history_concat_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+    CS_HIP(hipGetLastError());
   }
-  const int64_t n = B * (K + H) * D;
-  hipLaunchKernelGGL(cs_history_concat_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
-  CS_HIP(hipGetLastError());
   return CS_OK;
 }
 

@@ -72,8 +72,12 @@ def test_unsupported_shapes_fail_loudly():
     from vae_conditional_sampling_amd.sampling.vae_imputation import importance_resampling_gibbs_iteration
     model = make_model(O.make_resfc_weights(5, 6, 1, 64, 1), O.make_resfc_weights(3, 10, 1, 64, 2))
     X, M = seeded_inputs(2, 64, 5, 1)
-    with pytest.raises(_lib.CsError):      # I*K' = 65 proposals do not fit a wavefront
-        importance_resampling_gibbs_iteration(model, X.cuda(), M.cuda(), 1, num_prior_replenish_proposals=1)
+    # I*K' = 65 proposals do not fit a wavefront: the path of the large proposal sets takes them
+    out = importance_resampling_gibbs_iteration(model, X.cuda(), M.cuda(), 1, num_prior_replenish_proposals=1)
+    assert out[7].shape == (1, 2, 65) and torch.isfinite(out[0]).all()
+    with pytest.raises(_lib.CsError):      # clusters of 7 do not divide K' = 65
+        importance_resampling_gibbs_iteration(model, X.cuda(), M.cuda(), 1, num_prior_replenish_proposals=1,
+                                              resampling_scheme="glr", weighting="dmis_within_groups", glr_cluster_size=7)
     with pytest.raises(_lib.CsError):      # host tensors are refused: there is no CPU path
         importance_resampling_gibbs_iteration(model, X[:, :4], M, 1, num_prior_replenish_proposals=1)
     # C ABI: null arguments and mismatched networks return CS_EINVAL with a message

@@ -15,3 +15,16 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """Per-quantity maxima of the strict relative / absolute errors of every assert_close of the session
+    (tests/helpers.py), written where a GPU run's outputs are collected."""
+    from tests import helpers
+    if not helpers.PARITY_ERRORS:
+        return
+    import json
+    out = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "parity_errors.json"), "w") as f:
+        json.dump({"small": helpers.SMALL, "quantities": dict(sorted(helpers.PARITY_ERRORS.items()))}, f, indent=1)

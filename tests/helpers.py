@@ -40,12 +40,105 @@ def rel_err(a, b):
     return float(np.max(np.abs(a - b) / (np.abs(b) + 1.0))) if a.size else 0.0
 
 
+# The bar of every float comparison, in strict form: an entry of magnitude >= 1 must agree to rtol RELATIVE
+# (|a-b| <= rtol |b|), a smaller one to rtol ABSOLUTE.  Strict relative agreement cannot be asked of the small entries:
+# log-weights, imputations and network outputs are sums of O(1)..O(100) terms, and an entry that those terms cancel
+# down to 1e-3 still carries their float32 rounding (~1e-7 absolute), whatever evaluates it -- the exact-float32
+# kernels and the reference's own torch evaluation in another summation order included.  What the small entries do
+# is recorded instead: every comparison also notes the largest |a-b| / |b| over |b| > 1e-3 and the largest |a-b|
+# below that; tests/conftest.py writes the per-quantity maxima of a session to gpurun_out/parity_errors.json, and
+# profiles/r3_parity_errors.json is that file from the full GPU suite (largest strict relative error above 1e-3:
+# log-weights 1.3e-3, imputations 5e-4, at entries of magnitude ~1e-3 and absolute error ~1e-6; the same order
+# under the exact-float32 kernels).
+SMALL = 1e-3
+PARITY_ERRORS = {}
+
+
+def strict_errors(a, b, threshold):
+    """(largest |a-b| / |b| over |b| > threshold, largest |a-b| over the other entries), finite entries only."""
+    a = np.asarray(a, dtype=np.float64).ravel()
+    b = np.asarray(b, dtype=np.float64).ravel()
+    ok = np.isfinite(a) & np.isfinite(b)
+    a, b = a[ok], b[ok]
+    big = np.abs(b) > threshold
+    rel = float(np.max(np.abs(a[big] - b[big]) / np.abs(b[big]))) if big.any() else 0.0
+    ab = float(np.max(np.abs(a[~big] - b[~big]))) if (~big).any() else 0.0
+    return rel, ab
+
+
+def _record(what, a, b, rel1, abs1):
+    import re
+    try:
+        from vae_conditional_sampling_amd import _lib
+        arith = {0: "f32", 1: "bf16x3", 2: "bf16", 3: "f16x2"}.get(int(_lib.lib().cs_get_mlp_arith()), "?")
+    except Exception:
+        arith = "?"
+    key = arith + ":" + re.sub(r"\[\d+\]", "[t]", what)
+    rel, ab = strict_errors(a, b, SMALL)
+    r = PARITY_ERRORS.setdefault(key, {"rel_above_1": 0.0, "abs_below_1": 0.0, "rel_above_1e-3": 0.0, "abs_below_1e-3": 0.0,
+                                       "comparisons": 0, "entries": 0})
+    for k, v in (("rel_above_1", rel1), ("abs_below_1", abs1), ("rel_above_1e-3", rel), ("abs_below_1e-3", ab)):
+        r[k] = max(r[k], v)
+    r["comparisons"] += 1
+    r["entries"] += int(np.asarray(a).size)
+
+
 def assert_close(a, b, what, rtol=RTOL):
     a = a.detach().cpu().numpy() if torch.is_tensor(a) else np.asarray(a)
     b = b.detach().cpu().numpy() if torch.is_tensor(b) else np.asarray(b)
     assert a.shape == b.shape, f"{what}: shape {a.shape} vs {b.shape}"
-    e = rel_err(a, b)
-    assert e <= rtol, f"{what}: relative error {e:.3e} > {rtol:.1e}"
+    assert np.array_equal(np.isfinite(a), np.isfinite(b)), f"{what}: non-finite entries differ"
+    nf = ~np.isfinite(b)
+    assert np.array_equal(a[nf], b[nf], equal_nan=True), f"{what}: non-finite entries differ"
+    rel1, abs1 = strict_errors(a, b, 1.0)
+    _record(what, a, b, rel1, abs1)
+    assert rel1 <= rtol, f"{what}: relative error {rel1:.3e} > {rtol:.1e} (entries of magnitude >= 1)"
+    assert abs1 <= rtol, f"{what}: absolute error {abs1:.3e} > {rtol:.1e} (entries of magnitude < 1)"
+
+
+# A resampling index may only differ from the reference's where the draw's float64 uniform lies this close to the
+# steps of the reference's CDF that separate the two choices
+U_TOL = 1e-5
+
+
+def group_members(scheme, I, Kp, cluster):
+    """Per resampling group the flattened '(i k)' indices of its members in member order, and per output slot
+    (group, draw) -> slot index, for gr and glr."""
+    if scheme == "gr":
+        return [list(range(I * Kp))], lambda g, t: t
+    G = Kp // cluster
+    groups = [[i * Kp + kp for i in range(I) for kp in range(g, Kp, G)] for g in range(G)]
+    return groups, lambda g, t: t * G + g
+
+
+def check_indices(idx_gpu, idx_ref, log_w_ref, u, scheme, I, Kp, cluster, what=""):
+    """idx[B,NS]: equal, or explained by a uniform within U_TOL of the CDF steps between the two choices.
+    Returns the boolean [B,NS] array of slots that agree."""
+    idx_gpu, idx_ref = np.asarray(idx_gpu), np.asarray(idx_ref)
+    same = idx_gpu == idx_ref
+    if same.all():
+        return same
+    B = idx_ref.shape[0]
+    groups, slot_of = group_members(scheme, I, Kp, cluster)
+    c = Kp if scheme == "gr" else cluster
+    lw = np.asarray(log_w_ref, dtype=np.float64).transpose(1, 0, 2).reshape(B, I * Kp)
+    u = np.asarray(u, dtype=np.float64).reshape(B, len(groups), c)
+    bad = 0
+    for b, slot in zip(*np.nonzero(~same)):
+        g, t = next((g, t) for g in range(len(groups)) for t in range(c) if slot_of(g, t) == slot)
+        mem = groups[g]
+        w = lw[b, mem]
+        p = np.exp(w - w.max())
+        cdf = np.cumsum(p / p.sum())
+        pg, pr = mem.index(int(idx_gpu[b, slot])), mem.index(int(idx_ref[b, slot]))
+        lo, hi = min(pg, pr), max(pg, pr)
+        uu = u[b, g, t]
+        if not (abs(cdf[lo] - uu) <= U_TOL and abs(cdf[hi - 1] - uu) <= U_TOL):
+            bad += 1
+    n_diff = int((~same).sum())
+    assert bad == 0, f"{what}: {bad} of {n_diff} differing indices are not explained by a uniform at a CDF step"
+    assert n_diff <= max(2, int(2e-3 * same.size)), f"{what}: {n_diff} of {same.size} indices differ"
+    return same
 
 
 def make_model(enc_w, dec_w, latent_dist="normal_with_eps", gen_dist="normal_with_eps", device="cuda"):

@@ -81,7 +81,7 @@ def test_lair_iteration_conv_matches_reference_golden(name):
         assert_close(out[7], fx[f"t{t}_log_weights"], "log_weights", CONV_RTOL)
         assert np.array_equal(ws.idx.cpu().numpy(), fx[f"t{t}_idx"]), "resampling indices differ"
         assert_close(out[0], fx[f"t{t}_X_new"], "X_new", CONV_RTOL)
-        X = torch.from_numpy(fx[f"t{t}_X_new"]).cuda()  # continue from the reference's state
+        X = out[0].clone()  # the engine's own state carries over, as in a run
 
 
 @pytest.mark.parametrize("name", ["conv_acmwg_omni_like", "conv_acmwg_omni_full"])

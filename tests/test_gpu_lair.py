@@ -13,7 +13,7 @@ import torch
 # to 1e-4 (the 1e-5 bar applies to the log-weights and imputations themselves).
 DIAG_RTOL = 1e-4
 
-from tests.helpers import (RTOL, assert_close, load_golden, make_model, seeded_inputs, weights_from_fixture)
+from tests.helpers import (RTOL, assert_close, check_indices, load_golden, make_model, seeded_inputs, weights_from_fixture)
 
 pytestmark = pytest.mark.gpu
 
@@ -133,6 +133,10 @@ def run_lair_case(name):
     dict(B=190, K=16, R=1, I=1, D=8, Zd=16, H=256, nbe=2, nbd=2),      # GAS shape
     dict(B=33, K=20, R=5, I=1, D=43, Zd=32, H=256, nbe=5, nbd=2, scheme="glr", weighting="dmis_within_groups", cluster=5),
     dict(B=65, K=3, R=2, I=3, D=12, Zd=8, H=128, nbe=1, nbd=1, method="systematic"),
+    # more than 20 480 network rows per launch: the launches take the kernel variant of the large batches and
+    # run in more than one round of workgroups
+    dict(B=8192, K=4, R=1, I=1, D=43, Zd=32, H=256, nbe=5, nbd=2),     # MiniBooNE shape
+    dict(B=2048, K=16, R=1, I=1, D=21, Zd=16, H=256, nbe=2, nbd=2),    # HEPMASS shape
 ])
 def test_lair_iteration_matches_oracle_at_dataset_shapes(O, cfg):
     from vae_conditional_sampling_amd.sampling.vae_imputation import importance_resampling_gibbs_iteration
@@ -161,11 +165,17 @@ def test_lair_iteration_matches_oracle_at_dataset_shapes(O, cfg):
     assert_close(ws.gen_ll, o["gen_loglik"], "generator log-likelihood")
     assert_close(out[7], o["log_weights"], "log_weights")
     idx_gpu = ws.idx.cpu()
-    mism = (idx_gpu != o["idx_global"]).any(dim=1)
-    # An index may only differ where the uniform falls within float32 rounding of a CDF step;
-    # at these sizes (<= 5e3 draws, CDF agreement ~1e-6) none does with this seed.
-    assert not mism.any(), f"{int(mism.sum())} examples with differing resampling indices"
-    assert_close(out[0], o["X_new"], "X_new")
+    if method == "multinomial":
+        # An index may only differ where the uniform falls within float32 rounding of a CDF step: none does at the
+        # smaller sizes with this seed; among the 4e4 draws of the large batches a few may, and are checked to.
+        same = check_indices(idx_gpu.numpy(), o["idx_global"].numpy(), o["log_weights"].numpy(), draws["u_res"].numpy(),
+                             scheme, I, Kp, cluster, str(cfg))
+        assert B >= 2048 or same.all()
+        ok = torch.from_numpy(same[:, :K])
+        assert_close(out[0].cpu()[ok], o["X_new"][ok], "X_new")
+    else:
+        assert torch.equal(idx_gpu, o["idx_global"]), "resampling indices differ"
+        assert_close(out[0], o["X_new"], "X_new")
     assert_close(out[1], o["ess"], "ess", DIAG_RTOL)
     assert_close(out[3], o["perplexity"], "perplexity", DIAG_RTOL)
 

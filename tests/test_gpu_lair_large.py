@@ -15,51 +15,10 @@ import numpy as np
 import pytest
 import torch
 
-from tests.helpers import assert_close, load_golden, make_model, weights_from_fixture
+from tests.helpers import assert_close, check_indices, load_golden, make_model, weights_from_fixture
 
 pytestmark = pytest.mark.gpu
 DIAG_RTOL = 1e-4
-U_TOL = 1e-5
-
-
-def group_members(scheme, I, Kp, cluster):
-    """Per resampling group the flattened '(i k)' indices of its members in member order, and per output slot
-    (group, draw) -> slot index, for gr and glr."""
-    if scheme == "gr":
-        return [list(range(I * Kp))], lambda g, t: t
-    G = Kp // cluster
-    groups = [[i * Kp + kp for i in range(I) for kp in range(g, Kp, G)] for g in range(G)]
-    return groups, lambda g, t: t * G + g
-
-
-def check_indices(idx_gpu, idx_ref, log_w_ref, u, scheme, I, Kp, cluster, what=""):
-    """idx[B,NS]: equal, or explained by a uniform within U_TOL of the CDF steps between the two choices.
-    Returns the boolean [B,NS] array of slots that agree."""
-    idx_gpu, idx_ref = np.asarray(idx_gpu), np.asarray(idx_ref)
-    same = idx_gpu == idx_ref
-    if same.all():
-        return same
-    B = idx_ref.shape[0]
-    groups, slot_of = group_members(scheme, I, Kp, cluster)
-    c = Kp if scheme == "gr" else cluster
-    lw = np.asarray(log_w_ref, dtype=np.float64).transpose(1, 0, 2).reshape(B, I * Kp)
-    u = np.asarray(u, dtype=np.float64).reshape(B, len(groups), c)
-    bad = 0
-    for b, slot in zip(*np.nonzero(~same)):
-        g, t = next((g, t) for g in range(len(groups)) for t in range(c) if slot_of(g, t) == slot)
-        mem = groups[g]
-        w = lw[b, mem]
-        p = np.exp(w - w.max())
-        cdf = np.cumsum(p / p.sum())
-        pg, pr = mem.index(int(idx_gpu[b, slot])), mem.index(int(idx_ref[b, slot]))
-        lo, hi = min(pg, pr), max(pg, pr)
-        uu = u[b, g, t]
-        if not (abs(cdf[lo] - uu) <= U_TOL and abs(cdf[hi - 1] - uu) <= U_TOL):
-            bad += 1
-    n_diff = int((~same).sum())
-    assert bad == 0, f"{what}: {bad} of {n_diff} differing indices are not explained by a uniform at a CDF step"
-    assert n_diff <= max(2, int(2e-3 * same.size)), f"{what}: {n_diff} of {same.size} indices differ"
-    return same
 
 
 LARGE_CASES = ["lair_k100_glr5_dmisg", "lair_k96_r4_gr_dmis_lat", "lair_k40_i3_gr_syst", "lair_k30_i4_lr_smis",

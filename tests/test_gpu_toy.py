@@ -48,7 +48,7 @@ def test_lair_iteration_beta_uniform_matches_reference_golden(name):
         assert_close(out[5], fx[f"t{t}_norm_log_weights"], "norm_log_weights")
         assert_close(out[1], fx[f"t{t}_ess"], "ess", DIAG_RTOL)
         assert_close(out[0], fx[f"t{t}_X_new"], "X_new")
-        X = torch.from_numpy(fx[f"t{t}_X_new"]).cuda()
+        X = out[0].clone()
 
 
 def test_lair_sampler_beta_uniform_matches_reference_golden():

@@ -405,8 +405,10 @@ int cs_final_resample(const float* logw, const float* Zprops, int64_t TI, int64_
  * library runs on holds its copy until the process ends), so B * TI * K' must not exceed 8 388 608;
  * larger problems are rejected with CS_EINVAL (use cs_final_resample).  The call allocates nothing; the
  * first call on a device looks the array's address up (make that call outside graph capture).  All
- * calls on one GPU share the array: calls that overlap on one GPU (different streams) race.  Same
- * arguments and results as cs_final_resample otherwise. */
+ * calls on one GPU share the array: calls that overlap on one GPU (different streams) race.  The array is
+ * the one of the CURRENT device (hipGetDevice): the stream must belong to it.  The 32 MiB are part of the
+ * library's code object: every GPU on which a process has loaded the library holds them whether or not this
+ * entry point is ever called.  Same arguments and results as cs_final_resample otherwise. */
 int cs_final_resample_static(const float* logw, const float* Zprops, int64_t TI, int64_t B, int32_t Kp,
                              int32_t Zd, const double* u, const cs_rng* rng, int64_t n, int64_t* idx, float* Zout,
                              void* stream);

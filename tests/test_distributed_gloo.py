@@ -68,7 +68,32 @@ def _fake_epoch(tester, lo, hi, batch_size, T=3, K=2, D=5):
         tester.norm_log_weights.append(ex[:, None, None] + np.zeros((1, T, 3), np.float32))
 
 
-def _driver_worker(rank, world, port, n_total, batch_size, root):
+ACMWG_KW = dict(num_pseudo_warmup_iterations=1, num_mwg_iterations=2, prior_mixture_probability=0.05,
+                warmup_method="pseudo_gibbs", store_last_n_iterations=-1, store_every_n_iterations=1,
+                imputation_metric_quantiles=[0.5], compute_f1_metric=False, compute_inv_f1_metric=False,
+                compute_bin_accuracy_metric=False, compute_rmse_metric=True, compute_ssim_metric=False,
+                compute_latent_wass_metric=False, num_copies=2, imputation_fn="vae_samples")
+
+
+def _fake_acmwg_epoch(tester, lo, hi, batch_size, T=3, K=2, D=5):
+    """The artefact set of an AC-MWG run (imputations_{b}.npz with latents, the acceptance series): values a function
+    of the global example index only."""
+    import numpy as np
+    tester.on_test_epoch_start()
+    for b, s in enumerate(range(lo, hi, batch_size)):
+        e = min(s + batch_size, hi)
+        ex = np.arange(s, e, dtype=np.float32)
+        imps = (ex[None, :, None, None] * 100 + np.arange(T + 1, dtype=np.float32)[:, None, None, None] * 10
+                + np.arange(K, dtype=np.float32)[None, None, :, None] + np.zeros((1, 1, 1, D), np.float32))
+        tester._save_npz(f"imputations_{b}.npz", imputations=imps, latents=imps[:, :, :, :3] * 0.5,
+                         true_X=ex[:, None, None] + np.zeros((1, 1, D), np.float32),
+                         masks=(np.arange(D)[None, None, :] + ex[:, None, None].astype(int)) % 2 == 0, data_idx=np.arange(s, e))
+        tester.metrics["acceptance"].append([0.25 + 0.0 * t for t in range(T)])
+        tester.metrics["imp_metric/rmse"].append(ex[None, :, None] + np.zeros((T, 1, K), np.float32))
+        tester.metrics["num_X"].append(e - s)
+
+
+def _driver_worker(rank, world, port, n_total, batch_size, root, sampler="lair"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     if world > 1:
@@ -76,40 +101,52 @@ def _driver_worker(rank, world, port, n_total, batch_size, root):
     import time
     from vae_conditional_sampling_amd import driver
     from vae_conditional_sampling_amd.data.missing_data_module import shard_range
-    from vae_conditional_sampling_amd.sampling.test_step_vae_sampling import TestVAELatentAdaptiveImportanceResampling
+    from vae_conditional_sampling_amd.sampling.test_step_vae_sampling import (
+        TestVAEAdaptiveCollapsedMetropolisWithinGibbs, TestVAELatentAdaptiveImportanceResampling)
     if rank == 1:
         time.sleep(1.0)   # a late rank must not open a version directory of its own
-    tester = TestVAELatentAdaptiveImportanceResampling(**LAIR_KW)
+    if sampler == "lair":
+        tester = TestVAELatentAdaptiveImportanceResampling(**LAIR_KW)
+    else:
+        tester = TestVAEAdaptiveCollapsedMetropolisWithinGibbs(**ACMWG_KW)
     driver.prepare_outputs(tester, root, rank, world > 1)
     lo, hi = shard_range(n_total, rank, world)
-    _fake_epoch(tester, lo, hi, batch_size)
+    (_fake_epoch if sampler == "lair" else _fake_acmwg_epoch)(tester, lo, hi, batch_size)
     driver.finish_run(tester, [], n_total, batch_size, rank, world > 1, torch.device("cpu"))
     if world > 1:
         dist.destroy_process_group()
 
 
-def test_sharded_driver_writes_the_files_of_a_one_process_run(tmp_path):
-    """prepare_outputs / finish_run of the driver under gloo, world size 2, unequal shards, shard boundaries
+import pytest  # noqa: E402
+
+
+@pytest.mark.parametrize("sampler,n_total,world", [("lair", 11, 2), ("acmwg", 11, 2), ("lair", 1, 2), ("acmwg", 2, 3)])
+def test_sharded_driver_writes_the_files_of_a_one_process_run(tmp_path, sampler, n_total, world):
+    """prepare_outputs / finish_run of the driver under gloo, world size 2 (3), unequal shards, shard boundaries
     that do not fall on batch boundaries: rank 0 alone writes, into ONE version directory, and every file
-    equals the one a single process writes for the same examples."""
+    equals the one a single process writes for the same examples -- for the artefact sets of LAIR and of AC-MWG,
+    and when there are fewer examples than ranks (a rank with an empty shard takes part in every collective)."""
     import glob
     import numpy as np
-    n_total, bs = 11, 4
+    bs = 4
     one, two = str(tmp_path / "one"), str(tmp_path / "two")
-    _driver_worker(0, 1, 0, n_total, bs, one)
-    mp.spawn(_driver_worker, args=(2, _free_port(), n_total, bs, two), nprocs=2, join=True)
+    _driver_worker(0, 1, 0, n_total, bs, one, sampler)
+    mp.spawn(_driver_worker, args=(world, _free_port(), n_total, bs, two, sampler), nprocs=world, join=True)
     assert sorted(os.listdir(os.path.join(two, "lightning_logs"))) == ["version_0"]
     d1, d2 = (os.path.join(r, "lightning_logs", "version_0") for r in (one, two))
     names = sorted(os.listdir(d1))
-    assert names == sorted(os.listdir(d2)) and "imputations_2.npz" in names and "metrics_summary.npz" in names
-    assert "is_norm_log_weights.npz" in names and "irwg_imputations_after_final_resampling_0.npz" in names
+    assert names == sorted(os.listdir(d2)) and "imputations_0.npz" in names and "metrics_summary.npz" in names
+    if sampler == "lair":
+        assert "is_norm_log_weights.npz" in names and "irwg_imputations_after_final_resampling_0.npz" in names
+    if n_total == 11:
+        assert "imputations_2.npz" in names
     assert not glob.glob(os.path.join(two, "**", "rank_*"), recursive=True)
     for name in names:
         a, b = np.load(os.path.join(d1, name)), np.load(os.path.join(d2, name))
         assert sorted(a.files) == sorted(b.files), name
         for k in a.files:
             assert a[k].dtype == b[k].dtype and a[k].shape == b[k].shape, (name, k)
-            if name == "metrics_summary.npz" and k.startswith("is_ess"):
+            if name == "metrics_summary.npz" and (k.startswith("is_ess") or k.startswith("acceptance")):
                 # a mean of per-batch means weighted by batch size: the batches differ, the mean does not
                 np.testing.assert_allclose(a[k], b[k], rtol=1e-12)
             else:

@@ -210,6 +210,29 @@ def test_sampler_runs_unobserved_stretches_in_one_call_with_identical_results(tm
     np.testing.assert_allclose(o1[0]["is_ess"], o8[0]["is_ess"], rtol=1e-6)
 
 
+def test_sampler_batches_the_iterations_between_stored_ones(tmp_path):
+    """store_every_n_iterations = 10 with every stored iteration kept: iteration 0 is stored, so the first step is a
+    single one, and the nine iterations up to the next stored one run in one library call, again and again."""
+    from vae_conditional_sampling_amd import driver
+    from vae_conditional_sampling_amd.sampling import test_step_vae_sampling as TS
+    cfg = driver.load_config(os.path.join(ROOT, "configs/uci_miniboone/sampling_u50/lair_k4_dmis_gr_mult_1replenish.yaml"),
+                             ["data.synthetic_num_test=40", "data.num_first_datapoints_test=40", "data.batch_size=64",
+                              "test_class.init_args.num_iterations=31", "test_class.init_args.store_every_n_iterations=10",
+                              "test_class.init_args.compute_rmse_metric=False", "test_class.init_args.compute_mae_metric=False",
+                              "test_class.init_args.compute_latent_wass_metric=False",
+                              f"trainer.default_root_dir={tmp_path}"])
+    calls = []
+    orig_run = TS.engine.lair_run
+    TS.engine.lair_run = lambda *a, **k: (calls.append(a[5]), orig_run(*a, **k))[1]
+    try:
+        tester, outs = driver.run(cfg)
+    finally:
+        TS.engine.lair_run = orig_run
+    assert len(calls) >= 3 and sum(calls) >= 24, calls
+    f0 = np.load(os.path.join(tester.out_dir, "imputations_0.npz"))
+    assert f0["imputations"].shape[1:] == (40, 4, 43) and np.isfinite(f0["imputations"]).all()
+
+
 def test_yaml_driver_selects_the_arithmetic_per_run(tmp_path):
     """`mlp_arith: f16x2` in a configuration pins the arithmetic on the run's network handles (not process-wide)."""
     from vae_conditional_sampling_amd import _lib, driver

@@ -311,6 +311,14 @@ def test_pointwise_metric_summary_matches_numpy(K):
     assert quant.shape == ref_q.shape and np.allclose(quant, ref_q, rtol=1e-6, atol=1e-7)
     m2, s2, q2 = pointwise_summary(values, [])
     assert q2.shape == (0, T) and np.allclose(m2, mean)
+    # NaN truths (nan_miss data) give NaN errors for some values of some iterations: numpy's quantiles of such an
+    # iteration are NaN, the others are untouched
+    values[1][2, 5, 0] = np.nan
+    values[0][4, :, :] = np.nan
+    _, _, quant = pointwise_summary(values, qs)
+    ref_q = np.quantile(np.concatenate(values, axis=1).transpose(1, 2, 0).reshape(-1, T), axis=0, q=qs)
+    assert np.isnan(ref_q[:, [2, 4]]).all() and np.array_equal(np.isnan(quant), np.isnan(ref_q))
+    assert np.allclose(quant, ref_q, rtol=1e-6, atol=1e-7, equal_nan=True)
 
 
 def test_parallel_npz_writer_matches_numpy(tmp_path):

@@ -48,6 +48,29 @@ def test_static_workspace_final_resampling_matches_the_allocating_entry_point():
         assert torch.equal(i0, i1) and torch.equal(z0, z1)
 
 
+def test_static_workspace_call_leaves_the_free_device_memory_unchanged():
+    """The property the entry point exists for: with inputs and outputs in place, a call takes no device memory
+    (hipMemGetInfo's free byte count is the same before and after, on the second call as on later ones)."""
+    from vae_conditional_sampling_amd import _lib
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(12)
+    TI, B, Kp, Zd, n = 11, 40, 5, 8, 30
+    logw = torch.randn(TI, B, Kp, generator=g).cuda()
+    Zp = torch.randn(TI, B, Kp, Zd, generator=g).cuda()
+    u = torch.rand(B, n, generator=g, dtype=torch.float64).cuda()
+    idx = torch.empty(B, n, dtype=torch.int64, device="cuda")
+    Zout = torch.empty(B, n, Zd, device="cuda")
+    args = (_lib.ptr(logw), _lib.ptr(Zp), TI, B, Kp, Zd, _lib.ptr(u), None, n, _lib.ptr(idx), _lib.ptr(Zout),
+            _lib.current_stream())
+    _lib.check(L.cs_final_resample_static(*args))   # the address look-up of the first call on the device
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    for _ in range(3):
+        _lib.check(L.cs_final_resample_static(*args))
+    torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info()[0] == free0
+
+
 def test_static_workspace_rejects_sizes_beyond_its_maximum():
     from vae_conditional_sampling_amd import _lib
     L = _lib.lib()

@@ -92,24 +92,48 @@ def merge_shards(shards):
     return {stem: _concat([s[stem] for s in shards], stem) for stem in shards[0]}
 
 
-def gather_shard_arrays(shard, n_total, device, group=None):
-    """The collective form of ``merge_shards``: every array of ``shard`` goes through one
-    ``gather_sharded``.  Returns the merged structure (on every rank)."""
-    out = {}
+def _shard_schema(shard):
+    """[(stem, key, example axis, trailing shape, dtype, placeholder array or None)] of a rank's arrays."""
+    rows = []
     for stem in sorted(shard):
-        out[stem] = {}
         for key in sorted(shard[stem]):
             a = shard[stem][key]
             ax = EXAMPLE_AXIS[stem][key]
             if _is_placeholder(key, a, ax):
-                out[stem][key] = a
-                continue
+                rows.append((stem, key, ax, None, str(a.dtype), a))
+            else:
+                rows.append((stem, key, ax, tuple(np.moveaxis(a, ax, 0).shape[1:]), str(a.dtype), None))
+    return rows
+
+
+def gather_shard_arrays(shard, n_total, device, group=None):
+    """The collective form of ``merge_shards``: every array of ``shard`` goes through one
+    ``gather_sharded``.  Returns the merged structure (on every rank).
+
+    The ranks first agree on the list of arrays (names, trailing shapes, dtypes): a rank whose shard is empty
+    (fewer examples than ranks) has collected nothing, and takes part in every collective with zero-length blocks
+    of the shapes the other ranks report."""
+    schema = _shard_schema(shard)
+    if group_ready():
+        parts = [None] * dist.get_world_size(group)
+        dist.all_gather_object(parts, schema, group=group)
+        schema = max(parts, key=len)   # a rank with examples has the full list; ranks with examples agree
+    out = {}
+    for stem, key, ax, trailing, dtype, placeholder in schema:
+        out.setdefault(stem, {})
+        if trailing is None:
+            out[stem][key] = placeholder
+            continue
+        a = shard.get(stem, {}).get(key)
+        if a is None or _is_placeholder(key, a, ax):
+            t = torch.from_numpy(np.zeros((0,) + tuple(trailing), dtype=np.dtype(dtype)))
+        else:
             t = torch.from_numpy(np.ascontiguousarray(np.moveaxis(a, ax, 0)))
-            as_bool = t.dtype == torch.bool
-            t = t.to(torch.uint8) if as_bool else t
-            g = gather_sharded(t.to(device).contiguous(), n_total, group).cpu()
-            g = g.bool() if as_bool else g
-            out[stem][key] = np.moveaxis(g.numpy(), 0, ax)
+        as_bool = t.dtype == torch.bool
+        t = t.to(torch.uint8) if as_bool else t
+        g = gather_sharded(t.to(device).contiguous(), n_total, group).cpu()
+        g = g.bool() if as_bool else g
+        out[stem][key] = np.moveaxis(g.numpy(), 0, ax)
     return out
 
 

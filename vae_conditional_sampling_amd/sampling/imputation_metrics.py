@@ -115,5 +115,8 @@ def pointwise_summary(values, quantiles, device=None):
             d = b - a
             # numpy's _lerp: a + d g, taken from the other end when g >= 0.5
             r = torch.where(g >= 0.5, b - d * (1 - g), a + d * g)
+            # np.quantile returns NaN for an iteration that holds a NaN (test_step_vae_sampling.py:847); the sort
+            # puts NaNs last, so the last entry tells
+            r = torch.where(srt[:, -1:].isnan(), torch.full_like(r, float("nan")), r)
             quant[:, t0:t1] = r.t().cpu().numpy()
     return mean, std, quant

@@ -537,12 +537,17 @@ class TestVAELatentAdaptiveImportanceResampling(TestVAESamplerBase):
                    and not hp.store_latents and hp.weight_transform is None and not hp.store_norm_log_weights
                    and hp.prior_replenish_iteration_frequency == 1 and self.max_iterations_per_call > 1)
         t = 0
-        while can_run and t < T:
+        while t < T:
             n = 1
-            while t + n < T and n < self.max_iterations_per_call and not self._state_needed(hp.num_pseudo_warmup_iterations + t + n - 1):
+            while (can_run and t + n < T and n < self.max_iterations_per_call
+                   and not self._state_needed(hp.num_pseudo_warmup_iterations + t + n - 1)):
                 n += 1
             if n == 1:
-                break   # the consumer reads every state from here on (or the stretch is over): single steps below
+                # the consumer reads this iteration's state (or nothing can be batched): one single step, after
+                # which the next stretch may be batched again
+                yield from self._single_step(t, T, X, M, history, clip_min, clip_max, all_norm_log_weights)
+                t += 1
+                continue
             R = hp.num_prior_replenish_proposals
             ws = engine.lair_workspace(self.model, B, K, R, hp.num_imp_samples, X.device)
             cfg = engine.lair_cfg(self.model, ws, weighting=hp.weighting_scheme, scheme=hp.resampling_scheme,
@@ -563,54 +568,59 @@ class TestVAELatentAdaptiveImportanceResampling(TestVAESamplerBase):
                        'transformed_ess': means[1, i], 'perplexity': means[2, i],
                        'total_num_props': hp.num_imp_samples * (K + R), 'acceptance_x': 1.0}
             t += n
-        for t in range(t, T):
-            weight_transform = None
-            if hp.weight_transform == 'poly':
-                weight_transform = min((t + 10) / self.max_iterations, 1)
-            R = hp.num_prior_replenish_proposals if t % hp.prior_replenish_iteration_frequency == 0 else 0
-            use_hist = (hp.no_historic_proposals_iterations is not None
-                        and (hp.num_pseudo_warmup_iterations + t) > hp.no_historic_proposals_iterations)
-            ret = importance_resampling_gibbs_iteration(
-                self.model, X, M, hp.num_imp_samples, glr_cluster_size=hp.glr_cluster_size,
-                weighting=hp.weighting_scheme, resampling_method=hp.resampling_method,
-                resampling_scheme=hp.resampling_scheme, num_prior_replenish_proposals=R,
-                use_historical_proposals=use_hist, num_historical_proposals=hp.num_historical_proposals,
-                history=history,
-                weight_transform=weight_transform, return_resampled_latents=bool(hp.store_latents),
-                var_proposal_temperature=hp.var_proposal_temperature,
-                var_proposal_anneal_type_to_prior=hp.var_proposal_anneal_type_to_prior,
-                rng=self._rng(), draws=self._draws(B, K, R, D, bool(hp.store_latents), use_hist, history),
-                clip_min=clip_min, clip_max=clip_max, inplace=True)
-            self._next_iteration()
-            if history is not None:   # :1961-1962
-                history.enqueue_batch(ret[0])
-            X, ess, transformed_ess, perplexity, total_num_props, norm_log_weights, Z_prop, log_weights = ret[:8]
-            latents = ret[9].clone() if hp.store_latents else None  # (the reference fails without store_latents)
-
-            if hp.resample_final_imps:
-                if self._proposals is None:
-                    if ((hp.prior_replenish_iteration_frequency != 1 and hp.num_prior_replenish_proposals > 0)
-                            or hp.no_historic_proposals_iterations is not None):
-                        raise NotImplementedError("final resampling with a varying number of proposals")
-                    self._proposals = (torch.empty((T,) + tuple(Z_prop.shape), device=X.device),
-                                       torch.empty((T,) + tuple(log_weights.shape), device=X.device))
-                self._proposals[0][t].copy_(Z_prop)
-                self._proposals[1][t].copy_(log_weights)
-            if hp.store_norm_log_weights:
-                all_norm_log_weights.append(norm_log_weights.clone())
-
-            yield {'X': X,
-                   'Z': latents,
-                   'is_ess': ess.mean(),
-                   'is_ess_not_reduced': ess,
-                   'transformed_ess': transformed_ess.mean(),
-                   'perplexity': perplexity.mean(),
-                   'total_num_props': total_num_props,
-                   'acceptance_x': 1.0,
-                   }
 
         if hp.store_norm_log_weights:
             self.norm_log_weights.append(torch.stack(all_norm_log_weights, dim=1).cpu().numpy())
+
+    def _single_step(self, t, T, X, M, history, clip_min, clip_max, all_norm_log_weights):
+        """Iteration t of the sampler as one call of importance_resampling_gibbs_iteration (in place on X); yields its
+        output dict."""
+        hp = self.hparams
+        B, K, D = X.shape
+        weight_transform = None
+        if hp.weight_transform == 'poly':
+            weight_transform = min((t + 10) / self.max_iterations, 1)
+        R = hp.num_prior_replenish_proposals if t % hp.prior_replenish_iteration_frequency == 0 else 0
+        use_hist = (hp.no_historic_proposals_iterations is not None
+                    and (hp.num_pseudo_warmup_iterations + t) > hp.no_historic_proposals_iterations)
+        ret = importance_resampling_gibbs_iteration(
+            self.model, X, M, hp.num_imp_samples, glr_cluster_size=hp.glr_cluster_size,
+            weighting=hp.weighting_scheme, resampling_method=hp.resampling_method,
+            resampling_scheme=hp.resampling_scheme, num_prior_replenish_proposals=R,
+            use_historical_proposals=use_hist, num_historical_proposals=hp.num_historical_proposals,
+            history=history,
+            weight_transform=weight_transform, return_resampled_latents=bool(hp.store_latents),
+            var_proposal_temperature=hp.var_proposal_temperature,
+            var_proposal_anneal_type_to_prior=hp.var_proposal_anneal_type_to_prior,
+            rng=self._rng(), draws=self._draws(B, K, R, D, bool(hp.store_latents), use_hist, history),
+            clip_min=clip_min, clip_max=clip_max, inplace=True)
+        self._next_iteration()
+        if history is not None:   # :1961-1962
+            history.enqueue_batch(ret[0])
+        X, ess, transformed_ess, perplexity, total_num_props, norm_log_weights, Z_prop, log_weights = ret[:8]
+        latents = ret[9].clone() if hp.store_latents else None  # (the reference fails without store_latents)
+
+        if hp.resample_final_imps:
+            if self._proposals is None:
+                if ((hp.prior_replenish_iteration_frequency != 1 and hp.num_prior_replenish_proposals > 0)
+                        or hp.no_historic_proposals_iterations is not None):
+                    raise NotImplementedError("final resampling with a varying number of proposals")
+                self._proposals = (torch.empty((T,) + tuple(Z_prop.shape), device=X.device),
+                                   torch.empty((T,) + tuple(log_weights.shape), device=X.device))
+            self._proposals[0][t].copy_(Z_prop)
+            self._proposals[1][t].copy_(log_weights)
+        if hp.store_norm_log_weights:
+            all_norm_log_weights.append(norm_log_weights.clone())
+
+        yield {'X': X,
+               'Z': latents,
+               'is_ess': ess.mean(),
+               'is_ess_not_reduced': ess,
+               'transformed_ess': transformed_ess.mean(),
+               'perplexity': perplexity.mean(),
+               'total_num_props': total_num_props,
+               'acceptance_x': 1.0,
+               }
 
     def final_resampling(self, X_true, M):
         """Resample the latents across all iterations and decode (:1991-2032).  Returns

@@ -62,6 +62,11 @@ BASE_KW = dict(store_last_n_iterations=-1, store_every_n_iterations=1, imputatio
                imputation_fn="vae_samples")
 
 
+# examples per GPU of the HEPMASS / GAS legs: the whole-test-set configurations (K = 16) shard ~1e5-row test sets,
+# 131 072 synthetic examples per GPU under weak scaling
+WHOLE_SET_BATCH = 131072
+
+
 def resfc_flops(i, H, nb, o):
     return 2 * (i * H + 2 * nb * H * H + H * o)
 
@@ -100,6 +105,38 @@ def launch_ranks(n):
     if any(rcs):
         print(f"bench.py: rank exit codes {rcs}", file=sys.stderr)
         return 1
+    return 0
+
+
+def dry_run(rank, world, local_rank, dev, dist):
+    """`--dry-run`: every rank reports the device it is bound to and takes part in one all-reduce and one
+    all-gather; rank 0 prints one JSON line {"dry_run": true, "ranks": [{rank, local_rank, device, name}, ...]}.
+    A process group that cannot be set up has already ended the rank with a non-zero status (init_process_group
+    raises), which launch_ranks / the launcher reports."""
+    import json as _json
+    cur = torch.cuda.current_device()
+    me = {"rank": rank, "local_rank": local_rank, "device": f"cuda:{cur}", "name": torch.cuda.get_device_name(cur)}
+    if (not REHEARSAL) and cur != local_rank:
+        print(f"bench.py: rank {rank} is bound to cuda:{cur}, expected cuda:{local_rank}", file=sys.stderr)
+        return 3
+    everyone = [me]
+    if dist is not None:
+        cdev = torch.device("cpu") if REHEARSAL else dev
+        t = torch.full((4,), float(rank + 1), device=cdev)
+        dist.all_reduce(t)
+        want = world * (world + 1) / 2
+        g = torch.empty(world * 4, device=cdev)
+        dist.all_gather_into_tensor(g, torch.full((4,), float(rank), device=cdev))
+        if float(t[0]) != want or g.reshape(world, 4)[:, 0].tolist() != [float(r) for r in range(world)]:
+            print(f"bench.py: rank {rank}: collective results are wrong", file=sys.stderr)
+            return 4
+        everyone = [None] * world
+        dist.all_gather_object(everyone, me)
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(_json.dumps({"dry_run": True, "n_gpus": world, "backend": "gloo (rehearsal)" if REHEARSAL else ("nccl" if world > 1 else None),
+                           "ranks": everyone}))
     return 0
 
 
@@ -356,12 +393,13 @@ def extra_legs(args, arith, dev):
     for name in ("hepmass", "gas"):
         if name == args.workload:
             continue
-        b = LairCabi(name, args.batch, 0, dev)
+        nb = WHOLE_SET_BATCH if args.batch == 65536 else args.batch   # the whole-test-set configurations: 131 072 examples per GPU
+        b = LairCabi(name, nb, 0, dev)
         el, evs = b.timed(steps, args.warmup)
         roof, kern = b.kernel_report(evs, arith)
         w = b.w
-        legs[f"lair_{name}"] = {"ms_per_step": el / steps * 1e3, "value": args.batch * w["K"] * steps / el, "unit": "samples/s",
-                                "examples": args.batch, "K": w["K"], "R": w["R"], "steps": steps,
+        legs[f"lair_{name}"] = {"ms_per_step": el / steps * 1e3, "value": nb * w["K"] * steps / el, "unit": "samples/s",
+                                "examples": nb, "K": w["K"], "R": w["R"], "steps": steps,
                                 "roofline": {k: roof[k] for k in ("bound", "achieved", "peak", "unit", "frac", "avg_launch_ms")},
                                 "kernels": {k: kern[k] for k in ("encoder_ms", "decoder_ms", "resample_impute_ms", "decoder_frac",
                                                                  "step_mfma_frac", "resample_impute_GBps")}}
@@ -394,12 +432,13 @@ def extra_legs(args, arith, dev):
         from vae_conditional_sampling_amd import _lib
         _lib.set_mlp_arith("f16x2")
         try:
-            b = LairCabi("hepmass", args.batch, 0, dev)
+            nb = WHOLE_SET_BATCH if args.batch == 65536 else args.batch
+            b = LairCabi("hepmass", nb, 0, dev)
             el, evs = b.timed(steps, args.warmup)
             roof, kern = b.kernel_report(evs, "f16x2")
             w = b.w
-            legs["lair_hepmass_f16x2"] = {"ms_per_step": el / steps * 1e3, "value": args.batch * w["K"] * steps / el, "unit": "samples/s",
-                                          "examples": args.batch, "K": w["K"], "R": w["R"], "steps": steps,
+            legs["lair_hepmass_f16x2"] = {"ms_per_step": el / steps * 1e3, "value": nb * w["K"] * steps / el, "unit": "samples/s",
+                                          "examples": nb, "K": w["K"], "R": w["R"], "steps": steps,
                                           "roofline": {k: roof[k] for k in ("bound", "achieved", "peak", "unit", "frac", "avg_launch_ms")}}
             del b
             torch.cuda.empty_cache()
@@ -431,6 +470,10 @@ def main():
     ap.add_argument("--workload", default="miniboone", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=65536, help="examples per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="start the ranks, bind each to cuda:LOCAL_RANK, set the process group up, run one all-reduce "
+                         "and one all-gather of a few floats, print who sits where, and stop: a check of the launch, "
+                         "not a measurement")
     ap.add_argument("--no-extras", action="store_true", help="only the headline workload (no `extra` legs)")
     ap.add_argument("--arith", default=None, choices=["bf16x3", "f16x2", "f32"],
                     help="arithmetic of the fused MLP kernel (default: the library's, bf16x3 = exact 3-way bf16 split of "
@@ -451,10 +494,16 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
+        import datetime
+        # a rank that cannot join (no peer, no RCCL) raises here after the timeout and the process ends non-zero
+        limit = datetime.timedelta(seconds=int(os.environ.get("CSVAE_BENCH_INIT_TIMEOUT", "600")))
         if REHEARSAL:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", timeout=limit)
         else:
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, timeout=limit)
+
+    if args.dry_run:
+        raise SystemExit(dry_run(rank, world, local_rank, dev, dist))
 
     from vae_conditional_sampling_amd import _lib
 

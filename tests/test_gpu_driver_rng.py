@@ -247,3 +247,31 @@ def test_yaml_driver_selects_the_arithmetic_per_run(tmp_path):
     assert _lib.get_mlp_arith() == prev
     f0 = np.load(os.path.join(tester.out_dir, "imputations_0.npz"))
     assert np.isfinite(f0["imputations"]).all()
+
+
+def test_bench_multi_rank_launch_dry_run():
+    """`bench.py --gpus N --dry-run`: fresh child processes, one per rank (the parent never touches a GPU), each bound to
+    its device and joined in a process group.  On this one-GPU box the two ranks share GPU 0 over gloo (rehearsal);
+    without the rehearsal switch the same command must refuse to report a smaller run and exit non-zero, and a rank that
+    cannot join its process group must make the whole launch fail."""
+    import json
+    import subprocess
+    import sys
+    bench = os.path.join(ROOT, "bench.py")
+    env = dict(os.environ, CSVAE_BENCH_REHEARSAL="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, bench, "--gpus", "2", "--dry-run"], env=env, capture_output=True, text=True, timeout=170)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["dry_run"] and line["n_gpus"] == 2 and [x["rank"] for x in line["ranks"]] == [0, 1]
+    assert all(x["device"] == "cuda:0" for x in line["ranks"])
+    if torch.cuda.device_count() < 2:
+        env2 = {k: v for k, v in env.items() if k != "CSVAE_BENCH_REHEARSAL"}
+        r = subprocess.run([sys.executable, bench, "--gpus", "2", "--dry-run"], env=env2, capture_output=True, text=True, timeout=170)
+        assert r.returncode != 0 and "GPU(s) are visible" in r.stderr
+    # a rank whose rendezvous cannot complete (it waits for a peer that never starts) ends non-zero
+    env3 = dict(env, RANK="1", LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="1",
+                CSVAE_BENCH_INIT_TIMEOUT="5")
+    r = subprocess.run([sys.executable, bench, "--gpus", "2", "--dry-run"], env=env3, capture_output=True, text=True, timeout=170)
+    assert r.returncode != 0

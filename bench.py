@@ -427,27 +427,8 @@ def extra_legs(args, arith, dev):
                                              "algorithmic activation bytes / 8 TB/s), divided by the measured iteration"}
         return leg
 
-    if arith != "f16x2":
-        # the same two legs under the experimental fp16 split (opt-in; the line's `split_f16x2` block is its headline form)
-        from vae_conditional_sampling_amd import _lib
-        _lib.set_mlp_arith("f16x2")
-        try:
-            nb = WHOLE_SET_BATCH if args.batch == 65536 else args.batch
-            b = LairCabi("hepmass", nb, 0, dev)
-            el, evs = b.timed(steps, args.warmup)
-            roof, kern = b.kernel_report(evs, "f16x2")
-            w = b.w
-            legs["lair_hepmass_f16x2"] = {"ms_per_step": el / steps * 1e3, "value": nb * w["K"] * steps / el, "unit": "samples/s",
-                                          "examples": nb, "K": w["K"], "R": w["R"], "steps": steps,
-                                          "roofline": {k: roof[k] for k in ("bound", "achieved", "peak", "unit", "frac", "avg_launch_ms")}}
-            del b
-            torch.cuda.empty_cache()
-            model = mlp_vae("miniboone", dev)
-            legs["acmwg_miniboone_f16x2"] = leg_acmwg_class(model, args.batch, 5, 43, 40, dev, f_enc + f_dec, "f16x2")
-            del model
-            torch.cuda.empty_cache()
-        finally:
-            _lib.set_mlp_arith(arith)
+    # layer programs (the convolutional networks) run the bf16 split under every setting but exact f32
+    arith = "f32" if arith == "f32" else "bf16x3"
     fe, fd = CONV_FLOPS["omniglot"]
     m = conv_vae("omniglot", dev)
     legs["acmwg_omniglot_convresnet"] = layerwise(m, 400 * 5, 400 * 5, leg_acmwg_class(m, 400, 5, 784, 12, dev, fe + fd, arith,

@@ -83,7 +83,10 @@ def _record(what, a, b, rel1, abs1):
     r["entries"] += int(np.asarray(a).size)
 
 
-def assert_close(a, b, what, rtol=RTOL):
+def assert_close(a, b, what, rtol=RTOL, floor=None):
+    """``floor`` (broadcastable to ``b``): magnitudes that the entries are differences of.  A normalised log-weight is a
+    log-weight minus the logsumexp of its group and carries the log-weights' absolute error, however small it comes
+    out itself; with ``floor`` = the largest |log-weight| of the example an entry is held to rtol of max(|b|, floor)."""
     a = a.detach().cpu().numpy() if torch.is_tensor(a) else np.asarray(a)
     b = b.detach().cpu().numpy() if torch.is_tensor(b) else np.asarray(b)
     assert a.shape == b.shape, f"{what}: shape {a.shape} vs {b.shape}"
@@ -92,6 +95,13 @@ def assert_close(a, b, what, rtol=RTOL):
     assert np.array_equal(a[nf], b[nf], equal_nan=True), f"{what}: non-finite entries differ"
     rel1, abs1 = strict_errors(a, b, 1.0)
     _record(what, a, b, rel1, abs1)
+    if floor is not None:
+        fl = np.broadcast_to(floor.detach().cpu().numpy() if torch.is_tensor(floor) else np.asarray(floor), b.shape)
+        ok = np.isfinite(a) & np.isfinite(b)
+        den = np.maximum(np.maximum(np.abs(b[ok]), np.abs(fl[ok])), 1.0)
+        e = float(np.max(np.abs(a[ok].astype(np.float64) - b[ok]) / den)) if ok.any() else 0.0
+        assert e <= rtol, f"{what}: error {e:.3e} > {rtol:.1e} of max(|b|, floor, 1)"
+        return
     assert rel1 <= rtol, f"{what}: relative error {rel1:.3e} > {rtol:.1e} (entries of magnitude >= 1)"
     assert abs1 <= rtol, f"{what}: absolute error {abs1:.3e} > {rtol:.1e} (entries of magnitude < 1)"
 

@@ -126,7 +126,8 @@ def test_large_proposal_sets_match_oracle(cfg):
                                                 resampling_scheme=scheme, num_prior_replenish_proposals=R, draws=draws)
     ws = model._cs_workspaces[("lair", B, K, R, I, "cuda:0")]
     assert_close(out[7], o["log_weights"], "log_weights")
-    assert_close(out[5], o["norm_log_weights"], "norm_log_weights")
+    # random networks give log-weights in the hundreds: the normalised ones carry their absolute error
+    assert_close(out[5], o["norm_log_weights"], "norm_log_weights", floor=o["log_weights"].abs().amax(dim=(0, 2))[:, None])
     assert_close(out[1], o["ess"], "ess", DIAG_RTOL)
     assert_close(out[3], o["perplexity"], "perplexity", DIAG_RTOL)
     same = check_indices(ws.idx.cpu().numpy(), o["idx_global"].numpy(), o["log_weights"].numpy(), draws["u_res"].numpy(),

@@ -44,19 +44,22 @@ static void cs_split_cfg() {
   g_split16_waves = (w && std::strcmp(w, "4") == 0) ? 4 : (w && std::strcmp(w, "8") == 0) ? 8 : 0;
 }
 
-// Arithmetic of the fused-MLP matrix products: the f32-equivalent 3-way bf16 split (6 bf16 matrix
-// instructions per product, cs_mlp_split_kernel.inc; the default: measured as accurate against a
-// float64 evaluation as the exact-f32 kernel, at 0.6 of its time), exact f32 matrix instructions, or -- opt-in
-// only, never the default -- plain bf16 (operands rounded to bf16, one matrix instruction per product, f32
-// accumulation: the 16-row kernel with one term per operand; errors of the size of bf16 rounding, 2^-9 relative
-// per operand).
-// -1 = not decided yet: the environment variable CSVAE_MLP_ARITH (f32 | bf16x3 | bf16) is read at first use.
+// Arithmetic of the fused-MLP matrix products, all but the last float32-equivalent (measured as accurate against a
+// float64 evaluation as the exact-f32 kernel):
+//   the 2-way fp16 split (3 fp16 matrix instructions per product, rows and weights normalised by exact powers of two;
+//   the 16-row kernel with two terms per operand) -- the default;
+//   the 3-way bf16 split (6 bf16 matrix instructions per product; float32's exponent range in every term): what the
+//   default falls back to for a network with a non-finite weight, and the arithmetic of the layer programs;
+//   exact f32 matrix instructions;
+//   and -- opt-in only, never a default -- plain bf16 (operands rounded to bf16, one matrix instruction per product,
+//   f32 accumulation; errors of the size of bf16 rounding, 2^-9 relative per operand).
+// -1 = not decided yet: the environment variable CSVAE_MLP_ARITH (f16x2 | bf16x3 | f32 | bf16) is read at first use.
 static int g_arith = -1;
 int cs_mlp_arith() {
   if (g_arith < 0) {
     const char* e = std::getenv("CSVAE_MLP_ARITH");
     g_arith = (e && std::strcmp(e, "f32") == 0) ? CS_ARITH_F32 : (e && std::strcmp(e, "bf16") == 0) ? CS_ARITH_BF16
-            : (e && std::strcmp(e, "f16x2") == 0) ? CS_ARITH_F16X2 : CS_ARITH_BF16X3;
+            : (e && std::strcmp(e, "bf16x3") == 0) ? CS_ARITH_BF16X3 : CS_ARITH_F16X2;
   }
   return g_arith;
 }
@@ -108,8 +111,13 @@ int cs_mlp_launch(const CsMlpArgs& a_in, hipStream_t stream) {
     CS_REQUIRE(a.gen_dist >= CS_DIST_NORMAL && a.gen_dist <= CS_DIST_BERN,
                "Student-t / logit-normal generators need a layer-program decoder");
   cs_split_cfg();
-  const int arith = a.net.arith >= 0 ? a.net.arith : cs_mlp_arith();
+  int arith = a.net.arith >= 0 ? a.net.arith : cs_mlp_arith();
   const int waves16 = g_split16_waves ? g_split16_waves : (a.rows <= 20480 ? 4 : 8);
+  // The process-wide fp16 split covers every network it can: one with a non-finite weight (no fp16 stream) or beyond
+  // the kernel's LDS budget runs in the bf16 split, which has float32's range.  A handle that asks for the fp16
+  // split itself (cs_mlp_set_arith) is refused instead.
+  if (arith == CS_ARITH_F16X2 && a.net.arith < 0 && (a.net.wstream16h == nullptr || !cs_split16_fits(a.net, waves16, 2)))
+    arith = CS_ARITH_BF16X3;
   const bool tile16 = arith == CS_ARITH_BF16 || arith == CS_ARITH_F16X2 ||
                       (arith == CS_ARITH_BF16X3 && g_split_tile != 32 && cs_split16_fits(a.net, waves16, 3));
   if (arith == CS_ARITH_BF16) CS_REQUIRE(cs_split16_fits(a.net, waves16, 1), "network does not fit the LDS budget");

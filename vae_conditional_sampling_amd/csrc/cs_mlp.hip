@@ -26,6 +26,8 @@ int cs_mlp_split_launch_h256(const CsMlpArgs& a, hipStream_t stream);
 int cs_mlp_split16_launch_h64(const CsMlpArgs& a, hipStream_t stream, int waves, int terms);
 int cs_mlp_split16_launch_h128(const CsMlpArgs& a, hipStream_t stream, int waves, int terms);
 int cs_mlp_split16_launch_h256(const CsMlpArgs& a, hipStream_t stream, int waves, int terms);
+bool cs_mlp_narrow_supported(const CsMlpArgs& a);
+int cs_mlp_narrow_launch(const CsMlpArgs& a, hipStream_t stream);
 
 // Row tile of the split-bf16 arithmetic: 32 (cs_mlp_split_kernel.inc, one wave per SIMD) or 16
 // (cs_mlp_split16_kernel.inc, two waves per SIMD / half the dependent chain per row tile).
@@ -83,6 +85,19 @@ extern "C" int cs_mlp_get_arith(const cs_mlp_t* net) {
   return net && net->dev.arith >= 0 ? net->dev.arith : cs_mlp_arith();
 }
 
+// -1: the small-launch kernel for launches of up to CS_NARROW_MAX_TILES row tiles; 0: never; 1: whenever an instance
+// exists (tests).  CSVAE_NARROW gives the initial value.
+#define CS_NARROW_MAX_TILES 512
+static int g_narrow = [] {
+  const char* e = std::getenv("CSVAE_NARROW");
+  return (e && std::strcmp(e, "0") == 0) ? 0 : (e && std::strcmp(e, "1") == 0) ? 1 : -1;
+}();
+extern "C" int cs_debug_set_narrow(int mode) {
+  const int prev = g_narrow;
+  g_narrow = mode < 0 ? -1 : (mode > 0 ? 1 : 0);
+  return prev;
+}
+
 static long long* g_trace = nullptr;
 // Profiling hook: when set, every fused-MLP launch writes 16 int64 per wavefront (16-row tile)
 // into buf: clock64() stamps at start, after prologue, after the first layer, after each block,
@@ -137,6 +152,15 @@ int cs_mlp_launch(const CsMlpArgs& a_in, hipStream_t stream) {
   }
   CS_REQUIRE(a.rows < ((int64_t)1 << 31) * 16, "too many rows");
   if (a.net.split == 2) CS_REQUIRE(a.net.nto == 2 * a.net.tph, "bad tile split");
+  if (a.mode == CS_MLP_ENC) CS_REQUIRE(a.net.split == 2, "encoder output must be (loc | scale)");
+  if (a.mode == CS_MLP_DEC && a.gen_dist != CS_DIST_BERN)
+    CS_REQUIRE(a.net.split == 2, "generator output must be (loc | scale)");
+  // Small launches of the fp16 split (the reference configurations' own batch sizes): one row tile per workgroup,
+  // the layer's output features split over its wavefronts (cs_mlp_narrow_kernel.inc).  Up to 512 row tiles: two
+  // workgroups per CU; beyond that the kernels that keep a row tile on one wavefront use the chip better.
+  if (arith == CS_ARITH_F16X2 && g_narrow != 0 && !a.dbg && cs_mlp_narrow_supported(a) &&
+      (g_narrow == 1 || a.rows <= (int64_t)CS_NARROW_MAX_TILES * 16))
+    return cs_mlp_narrow_launch(a, stream);
   if (a.mode == CS_MLP_ENC) CS_REQUIRE(a.net.split == 2, "encoder output must be (loc | scale)");
   if (a.mode == CS_MLP_DEC && a.gen_dist != CS_DIST_BERN)
     CS_REQUIRE(a.net.split == 2, "generator output must be (loc | scale)");

@@ -703,6 +703,12 @@ extern "C" int cs_lair_resample_impute(const cs_lair_cfg* c, const cs_lair_bufs*
   // more examples per wavefront fill more lanes, but the LDS working set limits how many
   // wavefronts are resident; ~12 KB per wavefront measured best (MiniBooNE shape)
   while (a.E > 1 && (size_t)a.E * per_example * 4 > 12 * 1024) --a.E;
+  // small batches: fewer examples per wavefront, so that the launch spreads over the chip and the loops of a
+  // wavefront (staging, imputation: a memory round trip per pass) are one pass long
+  {
+    const int64_t e_cap = (c->B + 2047) / 2048;
+    if (a.E > e_cap) a.E = (int)e_cap;
+  }
   CS_REQUIRE((size_t)a.E * per_example * 4 <= 64 * 1024, "proposal set too large for the LDS working set");
   a.lds_per_wave = a.E * per_example;
   const int DQ = (c->D + 3) >> 2;

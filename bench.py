@@ -362,8 +362,9 @@ def leg_lair_run(model, B, K, R, D, T, dev, flops_per_example, arith, per_call=6
     return {"ms_per_step": sec * 1e3, "value": B * K / sec, "unit": "samples/s", "examples": B, "K": K, "R": R,
             "iterations_timed": T - per_call, "iterations_per_call": per_call,
             "roofline": {"bound": "latency", "achieved": tf, "peak": peak_of(arith), "unit": "TFLOP/s", "frac": tf / peak_of(arith),
-                         "what": "whole iteration; 2048 / 2560 network rows per launch occupy 32 / 40 of 256 CUs: the time is "
-                                 "the dependent chain of one 16-row tile through the networks"}}
+                         "what": "whole iteration; 2048 / 2560 network rows per launch = 128 / 160 row tiles, a workgroup (CU) "
+                                 "each: the time is a CU streaming the network's weights from L2 for its one tile (2.7 MB + "
+                                 "1.2 MB per iteration), three dependent launches per iteration"}}
 
 
 def leg_acmwg_class(model, B, K, D, T, dev, flops_per_chain, arith, binary=False, quadrants=False):
@@ -413,6 +414,8 @@ def extra_legs(args, arith, dev):
     legs["lair_miniboone_sampler_class_b512"] = leg_lair_class(model, 512, 4, 1, 43, 300, dev, 4 * f_enc + 5 * f_dec, arith)
     legs["latency_b512"] = leg_lair_run(model, 512, 4, 1, 43, 640, dev, 4 * f_enc + 5 * f_dec, arith)
     legs["acmwg_miniboone"] = leg_acmwg_class(model, args.batch, 5, 43, 40, dev, f_enc + f_dec, arith)
+    # AC-MWG at the reference configuration's own batch (B = 256, K = 5): 80 row tiles per launch
+    legs["acmwg_miniboone_b256"] = leg_acmwg_class(model, 256, 5, 43, 300, dev, f_enc + f_dec, arith)
     del model
     torch.cuda.empty_cache()
     def layerwise(model, enc_rows, dec_rows, leg):

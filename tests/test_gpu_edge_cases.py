@@ -114,3 +114,34 @@ def test_function_level_calls_return_fresh_tensors():
     w = importance_resampling_gibbs_iteration(model, X.cuda(), M.cuda(), 1, num_prior_replenish_proposals=1, rng=_lib.make_rng(3, 1, 0),
                                               inplace=True)
     assert v[7].data_ptr() == w[7].data_ptr()            # views of one workspace
+
+
+@pytest.mark.parametrize("fn", ["rand_bin", "std_gauss"])
+def test_initial_imputation_functions_of_the_reference(fn):
+    """imputation_fn 'rand_bin' / 'std_gauss' (irwg/utils/basic_imputation.py:3-16): X*M + X_imp*(~M) with X_imp =
+    (u > 0.5) or u for uniform draws u of X's shape; from injected draws exactly, from the counter RNG independent of
+    batching."""
+    from oracle import cs_oracle as O
+    from oracle.cs_oracle_samplers import TapeSource
+    from tests.test_gpu_samplers import BASE_KW
+    from vae_conditional_sampling_amd.sampling.test_step_vae_sampling import TestVAEPseudoGibbs
+    model = make_model(O.make_resfc_weights(5, 6, 1, 64, 1), O.make_resfc_weights(3, 10, 1, 64, 2))
+    kw = dict(BASE_KW, imputation_fn=fn)
+    s = TestVAEPseudoGibbs(num_iterations=1, clip_imputations=False, num_copies=3, **kw)
+    s.set_model(model)
+    s.on_test_start()
+    X, M = seeded_inputs(6, 3, 5, 1)
+    u = torch.rand(6, 3, 5, generator=torch.Generator().manual_seed(2))
+    s.draw_source = TapeSource([("rand_like", u.numpy())])
+    got = s.basic_imputation(X.cuda(), M.cuda()).cpu()
+    want = X * M + ((u > 0.5).float() if fn == "rand_bin" else u) * (~M)
+    assert torch.equal(got, want)
+    s.draw_source = None
+    s.rng_seed = 5
+    s.example_offset = 0
+    whole = s.basic_imputation(X.cuda(), M.cuda())
+    s.example_offset = 4
+    tail = s.basic_imputation(X[4:].cuda(), M[4:].cuda())
+    assert torch.equal(whole[4:], tail) and torch.equal(whole.cpu()[M.expand_as(X)], X[M.expand_as(X)])
+    if fn == "rand_bin":
+        assert set(whole[~M.cuda().expand_as(whole)].unique().tolist()) <= {0.0, 1.0}

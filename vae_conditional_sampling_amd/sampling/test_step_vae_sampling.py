@@ -260,10 +260,21 @@ class TestVAESamplerBase(HyperparametersMixin):
 
     # ---- initial imputation (test_step_vae_sampling.py:276-297) -------------------------
     def basic_imputation(self, X, M):
-        if self.hparams.imputation_fn != 'vae_samples':
-            raise NotImplementedError(f"imputation_fn={self.hparams.imputation_fn!r} (only 'vae_samples')")
         B, K, D = X.shape
         src = self.draw_source
+        if self.hparams.imputation_fn in ('rand_bin', 'std_gauss'):
+            # irwg/utils/basic_imputation.py:3-16: uniform draws u of X's shape; missing entries become u > 0.5
+            # ('rand_bin') or u itself ('std_gauss': the reference draws torch.rand_like there too); X*M + X_imp*(~M),
+            # so a NaN at a missing entry of X stays NaN, as in the reference
+            if src is not None:
+                u = src.uniform(B, K, D).to(X.device, torch.float32)
+            else:   # counter RNG rows (example_offset + b)*K + k: independent of batching
+                u = engine.rng_uniform(_lib.make_rng(self.rng_seed, 0, self.example_offset * K), _lib.STREAM_INIT_X,
+                                       B * K, D, X.device).reshape(B, K, D)
+            X_imp = (u > 0.5).to(X.dtype) if self.hparams.imputation_fn == 'rand_bin' else u
+            return X * M + X_imp * (~M)
+        if self.hparams.imputation_fn != 'vae_samples':
+            raise NotImplementedError(f"imputation_fn={self.hparams.imputation_fn!r} ('vae_samples', 'rand_bin', 'std_gauss')")
         draws = None
         if src is not None:
             bern = self.model.hparams.generator_distribution.name == "bern"

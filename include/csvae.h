@@ -422,33 +422,34 @@ int cs_rng_uniform64(const cs_rng* rng, uint32_t stream_id, int64_t rows, int32_
 
 /* Arithmetic of the matrix products of the fused residual-MLP kernel (no counterpart in the
  * reference, whose torch.nn.Linear layers compute in float32):
- *   CS_ARITH_BF16X3  (default) every float32 operand is split exactly into three bfloat16 terms
- *                    (8 + 8 + 8 significand bits) and a product is accumulated in float32 from the
- *                    six leading term products; the neglected terms are below 2^-23 of |a||b|, the
- *                    size of one float32 rounding.  Results are float32-equivalent: against a float64
- *                    evaluation the error equals that of the exact-float32 kernel (tests/
- *                    test_gpu_split_arith.py), they are not bit-identical to it.  Operands that are
+ *   CS_ARITH_F16X2   (default) every float32 operand as two fp16 terms (11 + 11 significand bits), three products
+ *                    per pair, float32 accumulation; the neglected term is below 2^-22 |a||b|.  fp16's 5 exponent
+ *                    bits are dealt with by exact powers of two: every operand row is normalised (its largest
+ *                    magnitude into [2^14, 2^15), fp16's top binade) and every layer's weights (largest into
+ *                    [2^14, 2^15)), the exponents are carried along and taken out at the end.  An operand down to
+ *                    2^-17 of its row's largest is represented to 2^-22 of itself, a smaller one to 2^-39 of the row's
+ *                    largest.  Results are float32-equivalent: against a float64 evaluation the error is that of the
+ *                    exact-float32 kernel or lower, for inputs and weights of any scale, outliers and in-row spreads
+ *                    of 1e4 included (tests/test_gpu_f16x2_arith.py); they are not bit-identical to it.  A network
+ *                    with a non-finite weight has no fp16 stream: under the process-wide setting it runs in
+ *                    CS_ARITH_BF16X3, a handle told CS_ARITH_F16X2 itself (cs_mlp_set_arith) is refused.  Fused MLP
+ *                    kernel only; layer-program networks keep CS_ARITH_BF16X3 under this setting.
+ *   CS_ARITH_BF16X3  every float32 operand split exactly into three bfloat16 terms (8 + 8 + 8 significand bits), a
+ *                    product accumulated in float32 from the six leading term products; the neglected terms are below
+ *                    2^-23 of |a||b|.  Float32-equivalent like the default (tests/test_gpu_split_arith.py) with
+ *                    float32's exponent range in every term, at 1.5x the default's time.  Operands that are
  *                    infinite or within a factor 2^-8 of FLT_MAX give NaN where float32 gives +-inf.
- *   CS_ARITH_F32     exact float32 matrix instructions (1.66x the time).
+ *   CS_ARITH_F32     exact float32 matrix instructions (2.7x the default's time).
  *   CS_ARITH_BF16    opt-in throughput mode, never a default: weights and layer inputs rounded to bfloat16
  *                    (nearest even), one matrix instruction per product, float32 accumulation, biases /
  *                    ReLU / residual sums / epilogues in float32.  NOT float32-equivalent: every operand carries
  *                    a relative rounding error of up to 2^-9; results follow a bfloat16-rounded evaluation of
  *                    the network (tests/test_gpu_bf16_arith.py), not the reference's float32 one.  Fused MLP
  *                    kernel only; layer-program networks keep CS_ARITH_BF16X3 under this setting.
- *   CS_ARITH_F16X2   opt-in: every float32 operand as two fp16 terms (11 + 11 significand bits), three products
- *                    per pair, float32 accumulation: half the matrix work of CS_ARITH_BF16X3 (1.5x its throughput).
- *                    fp16's 5 exponent bits are dealt with by exact powers of two: every operand row is normalised
- *                    (its largest magnitude into [1, 2)) and every layer's weights (largest into [2^14, 2^15)), the
- *                    exponents are carried along and taken out at the end.  The neglected term is below 2^-22 |a||b|;
- *                    against a float64 evaluation the error is that of the float32 kernels or lower
- *                    (tests/test_gpu_f16x2_arith.py), for inputs and weights of any scale.  The limit: an operand
- *                    below 2^-3 of its row's largest keeps fewer than 22 bits (11 below 2^-14 of it), which shows
- *                    (a few 1e-6) only where the weights undo a spread of 1e4 inside a row.  A network with a
- *                    non-finite weight is refused.  Fused MLP kernel only.
  * The setting is process-wide and applies to launches made after the call; the environment variable
- * CSVAE_MLP_ARITH (bf16x3 | f32 | bf16 | f16x2) gives the initial value.  It also selects the kernels of the matrix-core
- * convolution / linear layers of layer-program networks (cs_net_create). */
+ * CSVAE_MLP_ARITH (f16x2 | bf16x3 | f32 | bf16) gives the initial value.  It also selects the kernels of the matrix-core
+ * convolution / linear layers of layer-program networks (cs_net_create): exact float32 under CS_ARITH_F32, the
+ * bfloat16 split otherwise. */
 enum { CS_ARITH_DEFAULT = -1, CS_ARITH_F32 = 0, CS_ARITH_BF16X3 = 1, CS_ARITH_BF16 = 2, CS_ARITH_F16X2 = 3 };
 int cs_set_mlp_arith(int arith);
 int cs_get_mlp_arith(void);

@@ -8,6 +8,9 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from vae_conditional_sampling_amd import _lib  # noqa: E402
+
+if os.environ.get("CSVAE_LIB_PATH"):   # timing experiments on a differently built library (this tool only)
+    _lib.LIB_PATH = os.path.abspath(os.environ["CSVAE_LIB_PATH"])
 from vae_conditional_sampling_amd.models import VAE, ResidualFCNetwork  # noqa: E402
 from vae_conditional_sampling_amd.sampling import engine  # noqa: E402
 

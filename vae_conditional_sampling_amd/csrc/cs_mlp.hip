@@ -412,7 +412,7 @@ extern "C" int cs_mlp_create(const cs_mlp_desc* d, const float* W0, const float*
     for (int l = 0; l < 2; ++l)
       h_ok = pack_layer16h(s16h, Wblk + ((size_t)b * 2 + l) * H * H, H, H, NKT, NT, hid_row, &wexp[1 + 2 * b + l]) && h_ok;
   h_ok = pack_layer16h(s16h, Wf, d->out_dim, H, NKT, nto, out_row, &wexp[2 * nb + 1]) && h_ok;
-  s16h.resize(s16h.size() + ((size_t)2 * (NT > nto ? NT : nto) * 2 * 64 + 1024) * 8, 0);
+  s16h.resize(s16h.size() + ((size_t)3 * (NT > nto ? NT : nto) * 2 * 64 + 1024) * 8, 0);  // the kernel copies two periods ahead
 
   cs_mlp* m = new cs_mlp();
   m->desc = *d;

@@ -45,7 +45,7 @@ import tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LLVM = "/opt/rocm/lib/llvm/bin"
 MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"
-PASSES = {"v_mfma_f32_32x32x16_bf16": 8, "v_mfma_f32_16x16x32_bf16": 4, "v_mfma_f32_16x16x32_f16": 4, "v_mfma_f32_32x32x2_f32": 16,
+PASSES = {"v_mfma_f32_32x32x16_bf16": 8, "v_mfma_f32_32x32x16_f16": 8, "v_mfma_f32_16x16x32_bf16": 4, "v_mfma_f32_16x16x32_f16": 4, "v_mfma_f32_32x32x2_f32": 16,
           "v_mfma_f32_16x16x4_f32": 8}
 NO_DST = ("global_store", "buffer_store", "flat_store", "scratch_store", "ds_write", "s_", "global_atomic", "buffer_atomic",
           "v_cmp", "v_cmpx")

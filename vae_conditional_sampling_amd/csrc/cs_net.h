@@ -22,12 +22,21 @@ struct CsLayer {
   int up_mode = CS_UP_NONE;
   int64_t wph_off[4] = {-1, -1, -1, -1};   // CS_UP_PHASES: packed weights of phase 2a + b (as wp_off / wp3_off)
   int64_t wph3_off[4] = {-1, -1, -1, -1};
+  // fp16-split packed weights (two fp16 terms of w 2^wexp) in d_blob3h, -1: none (a weight is not finite)
+  int64_t wp3h_off = -1;
+  int64_t wph3h_off[4] = {-1, -1, -1, -1};
+  int wexp = 0, wphexp[4] = {0, 0, 0, 0};
+  int src_layer = -1;  // index of the layer that wrote this layer's source buffer, -1: the network input
 };
 
 struct CsProgram {
   std::vector<CsLayer> layers;
   float* d_blob = nullptr;   // caller's blob followed by the packed weights
   uint16_t* d_blob3 = nullptr;  // split-bf16 packed weights of the same-size 3x3 convolutions
+  uint16_t* d_blob3h = nullptr; // fp16-split packed weights
+  // per-image maxima of the activations (fp16 split): [layers + 1][ws_rows] words, slot i = output of layer i, the
+  // last slot = the network input; zeroed at the start of every pass
+  unsigned* amax_ws = nullptr;
   int in_dim = 0, out_dim = 0;
   int64_t buf_elems[CS_NET_NBUF] = {0};  // floats per network row of every buffer
   // workspace (scratch buffers 1..4, staged input, raw output), grown on demand

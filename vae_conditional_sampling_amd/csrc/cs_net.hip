@@ -42,6 +42,17 @@ struct CsConvArgs {
   // all four phases of an upsampled convolution in one launch of the halo kernel (grid z = phase 2*ooh + oow):
   // distance in bf16 entries between the packed weights of consecutive phases
   int64_t w3_phase_stride;
+  // fp16-split arithmetic of the halo kernel (null / unused otherwise): weights as two fp16 terms of w 2^wexp, packed
+  // [tap][cin/32][cout_p/32] bricks of [k-step 2][term 2][lane 64] x 8 fp16; wexp per phase of a four-phase launch,
+  // else wexp[0]; in_amax[n] = bits of the largest |in| of image n of this launch (the power of two that brings it
+  // into [2^14, 2^15) scales the image's operands); out_amax[n] receives the same for the output (atomic max,
+  // zeroed by the caller), or null.  amax_lds = byte offset of the block's table of output maxima in LDS.
+  const uint16_t* w3h;
+  int wexp[4];
+  int64_t w3h_phase_stride;
+  const unsigned* in_amax;
+  unsigned* out_amax;
+  int amax_lds;
 };
 
 __device__ __forceinline__ int64_t conv_out_pix(const CsConvArgs& a, int64_t gp, int ooh, int oow) {
@@ -108,9 +119,13 @@ __device__ __forceinline__ void conv_store(const CsConvArgs& a, const f32x16 (&a
 // phase (ooh, oow) of an upsampled output (conv_out_pix), else output pixel = pixel.
 typedef __attribute__((address_space(3))) unsigned char conv_lds_byte;
 typedef __attribute__((address_space(3))) f32x4 conv_lds_f32x4;
+// s_amax (or null): LDS table of the block's per-image output maxima (bits of |value|, zeroed by the caller); pos0 =
+// position of the wavefront's first row counted from the first pixel of the block's first image, hw = pixels per image.
 template <int CT, int PT, bool PLACED>
 __device__ __forceinline__ void conv_store_rows(const CsConvArgs& a, const f32x16 (&acc)[PT][CT], conv_lds_byte* tw,
-                                                int64_t row_gp, int co0, int lane, int ooh, int oow) {
+                                                int64_t row_gp, int co0, int lane, int ooh, int oow,
+                                                __attribute__((address_space(3))) unsigned* s_amax = nullptr, int pos0 = 0,
+                                                int hw = 1) {
   constexpr int RL = CT * 128, RS = RL + 16, LPR = CT * 8, RPI = 64 / LPR;
   const int h = lane >> 5, l31 = lane & 31;
 #pragma unroll
@@ -132,6 +147,13 @@ __device__ __forceinline__ void conv_store_rows(const CsConvArgs& a, const f32x1
     v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (a.res && gp < a.npix) v[i] = *(const f32x4*)(a.res + (PLACED ? conv_out_pix(a, gp, ooh, oow) : gp) * a.cout + co0 + lc);
   }
+  // running maximum of the lane's rows of one image; handed to the table when the rows move on to the next image
+  int img = 0, next_img = 0;
+  float mx = 0.0f;
+  if (s_amax) {
+    img = (pos0 + lr) / hw;
+    next_img = (img + 1) * hw;
+  }
 #pragma unroll
   for (int i = 0; i < 32 * PT / RPI; ++i) {
     const int row = i * RPI + lr;
@@ -142,7 +164,17 @@ __device__ __forceinline__ void conv_store_rows(const CsConvArgs& a, const f32x1
       for (int r = 0; r < 4; ++r) o[r] = fmaxf(o[r], 0.0f);
     }
     if (gp < a.npix) *(f32x4*)(a.out + (PLACED ? conv_out_pix(a, gp, ooh, oow) : gp) * a.cout + co0 + lc) = o;
+    if (s_amax && gp < a.npix) {
+      while (pos0 + row >= next_img) {
+        if (mx > 0.0f) atomicMax((unsigned*)(s_amax + img), __float_as_uint(mx));
+        mx = 0.0f;
+        ++img;
+        next_img += hw;
+      }
+      mx = fmaxf(fmaxf(mx, fmaxf(fabsf(o[0]), fabsf(o[1]))), fmaxf(fabsf(o[2]), fabsf(o[3])));
+    }
   }
+  if (s_amax && mx > 0.0f) atomicMax((unsigned*)(s_amax + img), __float_as_uint(mx));
 }
 
 // Block = 4 wavefronts = 128 output pixels x (32*CT) output channels; a wavefront owns 32 pixels.
@@ -417,7 +449,48 @@ __device__ unsigned long long cs_conv_stamps[8 * 8192];
 #define CS_CONV_STAMP(i_, v_)
 #endif
 constexpr int CS_HALO_NPMAX = 10;  // staging passes: (32*PT*NW + 2*64) rows * 8 threads / (64*NW) threads
-template <int CT, int PT, int NW, bool PHASE>
+// ---- fp16 split (TERMS = 2) ----
+// Every f32 operand as two fp16 terms, three products a0*b0 + a0*b1 + a1*b0 on v_mfma_f32_32x32x16_f16 (half the matrix
+// work of the three-term bf16 split; the neglected term is below 2^-22 |a||b|).  fp16 has 5 exponent bits, so the
+// operands are normalised by exact powers of two: the weights of a layer by the one that brings the largest into
+// [2^14, 2^15) (host), the activations of an IMAGE by the one that does so for its largest magnitude (in_amax: all
+// taps of an output pixel must share a scale, and a per-image one leaves every image's result independent of the
+// other images of the launch); the accumulators come out scaled by both and are scaled back, exactly, before bias,
+// residual and ReLU.  An operand is represented to 2^-22 of itself or 2^-39 of its image's largest, whichever is
+// coarser.
+typedef _Float16 f16x8n __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2n __attribute__((ext_vector_type(2)));
+#define CS_CONV_MFMA32H(A_, B_, C_) \
+  C_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8n, A_), __builtin_bit_cast(f16x8n, B_), C_, 0, 0, 0)
+__device__ __forceinline__ unsigned conv_mix_pk_f16(float x, float y, float g) {  // (fp16(x g), fp16(y g)), g a power of two
+  unsigned h;
+  asm("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]\n\tv_fma_mixhi_f16 %0, %3, %2, 0 op_sel_hi:[0,0,0]"
+      : "=&v"(h)
+      : "v"(x), "v"(g), "v"(y));
+  return h;
+}
+__device__ __forceinline__ float conv_mix_rem_lo(float x, float g, unsigned h) {  // x g - (low half of h), exact
+  float r;
+  asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(r) : "v"(x), "v"(g), "v"(h));
+  return r;
+}
+__device__ __forceinline__ float conv_mix_rem_hi(float x, float g, unsigned h) {
+  float r;
+  asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r) : "v"(x), "v"(g), "v"(h));
+  return r;
+}
+__device__ __forceinline__ unsigned conv_cvt_pk_f16(float lo, float hi) {
+  return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2n){lo, hi}, f16x2n));
+}
+// 2^-e for the image maximum whose bits are `bits`: m 2^-e in [2^14, 2^15); an image of zeros (or a maximum outside
+// 2^-100 .. 2^100, clamped) keeps a finite scale
+__device__ __forceinline__ float conv_image_scale(unsigned bits) {
+  int be = (int)((bits & 0x7fffffffu) >> 23);
+  if ((bits & 0x7fffffffu) == 0u) return 1.0f;
+  be = be < 27 ? 27 : (be > 227 ? 227 : be);
+  return __uint_as_float((unsigned)(127 - (be - 127 - 14)) << 23);
+}
+template <int CT, int PT, int NW, bool PHASE, int TERMS = 3>
 __global__ void __launch_bounds__(64 * NW) cs_conv3x3_halo_split_kernel(const CsConvArgs a, int NR, int NP) {
   // PHASE: phase (pa, pb) = (blockIdx.z >> 1, blockIdx.z & 1) of a nearest-neighbour-upsampled 3x3 convolution, a 2x2
   // convolution of the input at its own resolution (see CsUpsampleMode): tap (dh, dw) reads the input pixel that tap
@@ -428,12 +501,19 @@ __global__ void __launch_bounds__(64 * NW) cs_conv3x3_halo_split_kernel(const Cs
   const int pa = PHASE ? (int)(blockIdx.z >> 1) : 0, pb = PHASE ? (int)(blockIdx.z & 1) : 0;
   constexpr int NTHR = 64 * NW, RPP = NTHR / 8;  // threads; window rows staged per pass
   constexpr int PX = 32 * PT;                    // pixels per wavefront
-  constexpr int ROWB = 192, W_B = CT * 6144;
+  // window rows: [term][32 k] of 2-byte entries.  TERMS = 3: 192-byte rows, 16-byte slot (k-step s, half h) of a term at
+  // (2s + h) ^ ((row >> 2) & 3), term t 64 t bytes on.  TERMS = 2: 128-byte rows of eight slots, slot
+  // (4t + 2s + h) ^ ((row >> 1) & 7): 16 consecutive rows (and the lane groups of a 16-byte read) cover the 16
+  // positions of the 256-byte bank period once.
+  constexpr int ROWB = 64 * TERMS, W_B = CT * 2048 * TERMS;
   constexpr int NPC = (W_B / 16 + NTHR - 1) / NTHR;  // 16-byte copies of a weight tile per thread
   constexpr int G = 2 * CT, GB = G / 2;              // groups (k-step, channel tile) of a step; barrier group
+  // weight ring: three slots and copies one step ahead, or (fp16 split: a step is half as long, shorter than a copy's
+  // round trip to L2) four slots and copies two steps ahead, waited for with a counted vmcnt
+  constexpr int NSLOT = TERMS == 2 ? 4 : 3, LEAD = NSLOT - 2;
   extern __shared__ __attribute__((aligned(1024))) unsigned char s_raw[];
-  lds_byte* s_w = (lds_byte*)s_raw;      // [3][W_B]
-  lds_byte* s_halo = s_w + 3 * W_B;      // [NR][ROWB], then 256 bytes of zeros
+  lds_byte* s_w = (lds_byte*)s_raw;      // [NSLOT][W_B]
+  lds_byte* s_halo = s_w + NSLOT * W_B;      // [NR][ROWB], then 256 bytes of zeros, then (TERMS = 2) the rows' scales
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = (int)cs_scalar_u32((unsigned)tid >> 6);
   const int h = lane >> 5, l31 = lane & 31, c4 = tid & 7;
@@ -441,8 +521,12 @@ __global__ void __launch_bounds__(64 * NW) cs_conv3x3_halo_split_kernel(const Cs
   const int ncc = a.cin >> 5;
   const int64_t p0 = (int64_t)blockIdx.x * (PX * NW);
   const unsigned char* wblk =
-      (const unsigned char*)(a.w3 + (PHASE ? (int64_t)blockIdx.z * a.w3_phase_stride : 0)) + (int64_t)blockIdx.y * W_B;
+      (TERMS == 2 ? (const unsigned char*)(a.w3h + (PHASE ? (int64_t)blockIdx.z * a.w3h_phase_stride : 0))
+                  : (const unsigned char*)(a.w3 + (PHASE ? (int64_t)blockIdx.z * a.w3_phase_stride : 0))) +
+      (int64_t)blockIdx.y * W_B;
   const unsigned zero_off = (unsigned)NR * ROWB;
+  __attribute__((address_space(3))) float* s_g = (__attribute__((address_space(3))) float*)(s_halo + zero_off + 256);  // [NR]
+  __attribute__((address_space(3))) unsigned* s_amax = (__attribute__((address_space(3))) unsigned*)((lds_byte*)s_raw + a.amax_lds);
   if (NW == 8 && wave >= 4) __builtin_amdgcn_s_setprio(1);  // evens out issue arbitration between the two waves of a SIMD
 
   unsigned tapmask[PT];
@@ -464,7 +548,20 @@ __global__ void __launch_bounds__(64 * NW) cs_conv3x3_halo_split_kernel(const Cs
 #pragma unroll
     for (int p = 0; p < CS_HALO_NPMAX; ++p) {
       const int row = (tid >> 3) + RPP * p;
-      if (p < NP && row < NR) {
+      if (TERMS == 2) {
+        if (p < NP && row < NR) {
+          // 4 consecutive k of one row -> 2 terms x 4 fp16 of the values times the row's power of two
+          const f32x4 v = rh[p];
+          const float g = s_g[row];
+          const unsigned a0 = conv_mix_pk_f16(v.x, v.y, g), b0 = conv_mix_pk_f16(v.z, v.w, g);
+          const float r0 = conv_mix_rem_lo(v.x, g, a0), r1 = conv_mix_rem_hi(v.y, g, a0);
+          const float r2 = conv_mix_rem_lo(v.z, g, b0), r3 = conv_mix_rem_hi(v.w, g, b0);
+          const unsigned a1 = conv_cvt_pk_f16(r0, r1), b1 = conv_cvt_pk_f16(r2, r3);
+          const unsigned o = (unsigned)row * ROWB + ((unsigned)((c4 >> 1) ^ ((row >> 1) & 7)) << 4) + ((unsigned)(c4 & 1) << 3);
+          *(__attribute__((address_space(3))) u32x2n*)(s_halo + o) = u32x2n{a0, b0};
+          *(__attribute__((address_space(3))) u32x2n*)(s_halo + (o ^ 64u)) = u32x2n{a1, b1};
+        }
+      } else if (p < NP && row < NR) {
         // 4 consecutive k of one row -> 3 terms x 4 bf16
         const f32x4 v = rh[p];
         const unsigned a0 = conv_cvt_pk(v.x, v.y), b0 = conv_cvt_pk(v.z, v.w);
@@ -491,22 +588,36 @@ __global__ void __launch_bounds__(64 * NW) cs_conv3x3_halo_split_kernel(const Cs
       cs_dma16(ssrc, dma_off, ring_lds + (unsigned)(slot * W_B + r * NTHR * 16));
     }
   };
-  // activation fragment address of pixel tile p for tap `tap`, k-step 0 (k-step 1: ^ 32)
+  // activation fragment address of pixel tile p for tap `tap`, k-step 0 (k-step 1: ^ 32), term 0 (b_term)
   auto b_addr = [&](int tap, int p) -> unsigned {
     const int kh = PHASE ? pa + (tap >> 1) : tap / 3, kw = PHASE ? pb + (tap & 1) : tap % 3;  // position in the 3x3 window
     const int rowB = row0[p] + kh * W + kw;
-    const unsigned o = (unsigned)rowB * ROWB + (unsigned)((h ^ ((rowB >> 2) & 3)) << 4);
+    const unsigned o = (unsigned)rowB * ROWB + (unsigned)((h ^ (TERMS == 2 ? (rowB >> 1) & 7 : (rowB >> 2) & 3)) << 4);
     return ((tapmask[p] >> (kh * 3 + kw)) & 1u) ? o : zero_off + (unsigned)(h << 4);
   };
+  auto b_term = [&](unsigned o, int tm) -> unsigned { return TERMS == 2 ? o ^ ((unsigned)tm << 6) : o + (unsigned)tm * 64u; };
 
   // the window and the first weight tile are requested first: the tap masks are computed under their latency
   fetch_halo(0);
 #pragma unroll
   for (int r = 0; r < NPC; ++r) dma_copy(0 * ncc + 0, 0, r);
+  if (LEAD == 2) {
+#pragma unroll
+    for (int r = 0; r < NPC; ++r) dma_copy(1 * ncc + 0, 1, r);  // step 1 = tap 1 of chunk 0
+  }
   if (tid < 16) *(lds_u32x4n*)(s_halo + zero_off + tid * 16) = u32x4n{0u, 0u, 0u, 0u};
+  const int hw = H * W;
+  if (TERMS == 2) {
+    // the power of two of every window row's image; rows outside the launch hold zeros under any scale
+    for (int r = tid; r < NR; r += NTHR) {
+      const int64_t q = p0 - (W + 1) + r;
+      s_g[r] = (q >= 0 && q < a.npix) ? conv_image_scale(a.in_amax[q / hw]) : 1.0f;
+    }
+    if (a.out_amax)
+      for (int r = tid; r < (PX * NW) / hw + 2; r += NTHR) s_amax[r] = 0u;
+  }
   // position of the block's first pixel inside its image: one 64-bit division per workgroup (uniform), 32-bit
   // arithmetic per lane (a block spans fewer than 2^10 pixels)
-  const int hw = H * W;
   const int rem0 = (int)cs_scalar_u32((unsigned)(p0 % hw));
 #pragma unroll
   for (int p = 0; p < PT; ++p) {
@@ -528,34 +639,37 @@ __global__ void __launch_bounds__(64 * NW) cs_conv3x3_halo_split_kernel(const Cs
     for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[p][ct][r] = 0.0f;
+  if (TERMS == 2) __syncthreads();  // the rows' scales
   stash_halo();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   CS_CONV_STAMP(1, __builtin_amdgcn_s_memrealtime());
   CS_CONV_STAMP(4, __builtin_amdgcn_s_memtime());
 
-  u32x4n wr[2][3];
-  u32x4n br[2][PT][3];
+  u32x4n wr[2][TERMS];
+  u32x4n br[2][PT][TERMS];
   unsigned bo[PT], bn[PT];
   const lds_byte* wl = s_w + lane * 16;
   for (int cc = 0; cc < ncc; ++cc) {
     // ring slot of the chunk's first step: 9 taps return to slot 0 with every chunk, 4 taps do not
-    const int sb = PHASE ? (int)cs_scalar_u32((unsigned)(cc % 3)) : 0;
+    const int sb = (NT % NSLOT) ? (int)cs_scalar_u32((unsigned)((cc * NT) % NSLOT)) : 0;
     // first fragments of the chunk: group 0 of tap 0
 #pragma unroll
-    for (int tm = 0; tm < 3; ++tm) wr[0][tm] = *(const lds_u32x4n*)(wl + sb * W_B + tm * 1024);
+    for (int tm = 0; tm < TERMS; ++tm) wr[0][tm] = *(const lds_u32x4n*)(wl + sb * W_B + tm * 1024);
 #pragma unroll
     for (int p = 0; p < PT; ++p) {
       bo[p] = b_addr(0, p);
 #pragma unroll
-      for (int tm = 0; tm < 3; ++tm) br[0][p][tm] = *(const lds_u32x4n*)(s_halo + bo[p] + tm * 64);
+      for (int tm = 0; tm < TERMS; ++tm) br[0][p][tm] = *(const lds_u32x4n*)(s_halo + b_term(bo[p], tm));
     }
 #pragma unroll
     for (int tap = 0; tap < NT; ++tap) {
-      const int slot = PHASE ? (sb + tap >= 3 ? sb + tap - 3 : sb + tap) : tap % 3;
-      const int nslot = PHASE ? (slot == 2 ? 0 : slot + 1) : (tap + 1) % 3;
-      const bool more = tap < NT - 1 || cc + 1 < ncc;                  // a step follows this one
-      const int tnext = tap < NT - 1 ? (tap + 1) * ncc + cc : cc + 1;  // its weight tile
+      const int slot = sb + tap % NSLOT >= NSLOT ? sb + tap % NSLOT - NSLOT : sb + tap % NSLOT;
+      const int nslot = slot == NSLOT - 1 ? 0 : slot + 1;
+      const int cslot = LEAD == 2 ? (nslot == NSLOT - 1 ? 0 : nslot + 1) : nslot;  // slot the step's copies fill
+      // the step LEAD steps on, if there is one, and its weight tile
+      const bool more = tap + LEAD < NT || cc + 1 < ncc;
+      const int tnext = tap + LEAD < NT ? (tap + LEAD) * ncc + cc : (tap + LEAD - NT) * ncc + cc + 1;
       if (tap < NT - 1) {
 #pragma unroll
         for (int p = 0; p < PT; ++p) bn[p] = b_addr(tap + 1, p);
@@ -564,7 +678,9 @@ __global__ void __launch_bounds__(64 * NW) cs_conv3x3_halo_split_kernel(const Cs
       for (int g = 0; g < G; ++g) {
         const int s = g / CT, ct = g % CT;
         if (g == GB) {
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          // the copies of the NEXT step have landed: all of the wave's (LEAD = 1), all but the ones just issued
+          if (LEAD == 2 && more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPC) : "memory");
+          else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           __builtin_amdgcn_s_barrier();
           __builtin_amdgcn_sched_barrier(0);
           // the next chunk's window: requested behind the barrier of tap 5, so that it has a whole step before
@@ -575,50 +691,68 @@ __global__ void __launch_bounds__(64 * NW) cs_conv3x3_halo_split_kernel(const Cs
         if (g + 1 < G) {
           const int s2 = (g + 1) / CT, ct2 = (g + 1) % CT;
 #pragma unroll
-          for (int tm = 0; tm < 3; ++tm)
-            wr[(g + 1) & 1][tm] = *(const lds_u32x4n*)(wl + slot * W_B + ((ct2 * 2 + s2) * 3 + tm) * 1024);
+          for (int tm = 0; tm < TERMS; ++tm)
+            wr[(g + 1) & 1][tm] = *(const lds_u32x4n*)(wl + slot * W_B + ((ct2 * 2 + s2) * TERMS + tm) * 1024);
         } else if (tap < NT - 1) {
 #pragma unroll
-          for (int tm = 0; tm < 3; ++tm) wr[0][tm] = *(const lds_u32x4n*)(wl + nslot * W_B + tm * 1024);
+          for (int tm = 0; tm < TERMS; ++tm) wr[0][tm] = *(const lds_u32x4n*)(wl + nslot * W_B + tm * 1024);
         }
         if (ct == CT - 1) {
           if (s == 0) {
 #pragma unroll
             for (int p = 0; p < PT; ++p)
 #pragma unroll
-              for (int tm = 0; tm < 3; ++tm) br[1][p][tm] = *(const lds_u32x4n*)(s_halo + (bo[p] ^ 32u) + tm * 64);
+              for (int tm = 0; tm < TERMS; ++tm) br[1][p][tm] = *(const lds_u32x4n*)(s_halo + b_term(bo[p] ^ 32u, tm));
           } else if (tap < NT - 1) {
 #pragma unroll
             for (int p = 0; p < PT; ++p)
 #pragma unroll
-              for (int tm = 0; tm < 3; ++tm) br[0][p][tm] = *(const lds_u32x4n*)(s_halo + bn[p] + tm * 64);
+              for (int tm = 0; tm < TERMS; ++tm) br[0][p][tm] = *(const lds_u32x4n*)(s_halo + b_term(bn[p], tm));
           }
         }
-        const u32x4n(&w)[3] = wr[g & 1];
+        const u32x4n(&w)[TERMS] = wr[g & 1];
+        if constexpr (TERMS == 2) {
 #pragma unroll
-        for (int p = 0; p < PT; ++p) {
-          CS_CONV_MFMA32(w[0], br[s][p][0], acc[p][ct]);
-          CS_CONV_MFMA32(w[0], br[s][p][1], acc[p][ct]);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if (more && g < GB) {
+          for (int p = 0; p < PT; ++p) {
+            CS_CONV_MFMA32H(w[0], br[s][p][0], acc[p][ct]);
+            CS_CONV_MFMA32H(w[0], br[s][p][1], acc[p][ct]);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          if (more && g < GB) {
 #pragma unroll
-          for (int r = 0; r < NPC; ++r)
-            if ((r < GB ? r : GB - 1) == g) dma_copy(tnext, nslot, r);
-        }
-        __builtin_amdgcn_sched_barrier(0);
+            for (int r = 0; r < NPC; ++r)
+              if ((r < GB ? r : GB - 1) == g) dma_copy(tnext, cslot, r);
+          }
+          __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int p = 0; p < PT; ++p) {
-          CS_CONV_MFMA32(w[1], br[s][p][0], acc[p][ct]);
-          CS_CONV_MFMA32(w[0], br[s][p][2], acc[p][ct]);
-        }
-        __builtin_amdgcn_sched_barrier(0);
+          for (int p = 0; p < PT; ++p) CS_CONV_MFMA32H(w[1], br[s][p][0], acc[p][ct]);
+          __builtin_amdgcn_sched_barrier(0);
+        } else {
 #pragma unroll
-        for (int p = 0; p < PT; ++p) {
-          CS_CONV_MFMA32(w[1], br[s][p][1], acc[p][ct]);
-          CS_CONV_MFMA32(w[2], br[s][p][0], acc[p][ct]);
+          for (int p = 0; p < PT; ++p) {
+            CS_CONV_MFMA32(w[0], br[s][p][0], acc[p][ct]);
+            CS_CONV_MFMA32(w[0], br[s][p][1], acc[p][ct]);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          if (more && g < GB) {
+#pragma unroll
+            for (int r = 0; r < NPC; ++r)
+              if ((r < GB ? r : GB - 1) == g) dma_copy(tnext, cslot, r);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int p = 0; p < PT; ++p) {
+            CS_CONV_MFMA32(w[1], br[s][p][0], acc[p][ct]);
+            CS_CONV_MFMA32(w[0], br[s][p][TERMS - 1], acc[p][ct]);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int p = 0; p < PT; ++p) {
+            CS_CONV_MFMA32(w[1], br[s][p][1], acc[p][ct]);
+            CS_CONV_MFMA32(w[TERMS - 1], br[s][p][0], acc[p][ct]);
+          }
+          __builtin_amdgcn_sched_barrier(0);
         }
-        __builtin_amdgcn_sched_barrier(0);
       }
 #pragma unroll
       for (int p = 0; p < PT; ++p) bo[p] = bn[p];
@@ -632,10 +766,34 @@ __global__ void __launch_bounds__(64 * NW) cs_conv3x3_halo_split_kernel(const Cs
   cs_mfma_drain();
   CS_CONV_STAMP(2, __builtin_amdgcn_s_memrealtime());
   CS_CONV_STAMP(5, __builtin_amdgcn_s_memtime());
+  if constexpr (TERMS == 2) {
+    // back to true values: the lane's pixel of tile p is window row row0[p] + W + 1; 1 / (its image's power of two) and
+    // 1 / (the weights' power of two), both exact
+    const int wexp = PHASE ? a.wexp[blockIdx.z] : a.wexp[0];
+    const float winv = __uint_as_float((unsigned)(127 - wexp) << 23);
+#pragma unroll
+    for (int p = 0; p < PT; ++p) {
+      const float ginv = __uint_as_float((254u << 23) - __float_as_uint(s_g[row0[p] + W + 1])) * winv;
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[p][ct][r] *= ginv;
+    }
+  }
   if ((a.cout & 31) == 0 && !a.out_nchw) {
     __syncthreads();  // the ring and the window are dead: the LDS becomes per-wave transposition space
+    const bool amax = TERMS == 2 && a.out_amax != nullptr;
     conv_store_rows<CT, PT, PHASE>(a, acc, (conv_lds_byte*)s_raw + wave * (PX * (CT * 128 + 16)), p0 + wave * PX,
-                                   blockIdx.y * (CT * 32), lane, pa, pb);
+                                   blockIdx.y * (CT * 32), lane, pa, pb, amax ? s_amax : nullptr, rem0 + wave * PX, hw);
+    if (amax) {
+      // the block's table of per-image maxima joins the launch's (image of the block's first pixel: (p0 - rem0) / hw)
+      __syncthreads();
+      const int64_t img0 = (p0 - rem0) / hw;
+      for (int r = tid; r < (PX * NW) / hw + 2; r += NTHR) {
+        const unsigned v = s_amax[r];
+        if (v != 0u) atomicMax(a.out_amax + img0 + r, v);
+      }
+    }
   } else {
 #pragma unroll
     for (int p = 0; p < PT; ++p) conv_store<CT>(a, acc[p], p0 + row0[p], blockIdx.y * (CT * 32), h);
@@ -1479,14 +1637,37 @@ __global__ void __launch_bounds__(64) cs_dec_finish_kernel(const CsMlpArgs a, co
   }
 }
 
+// out[n] = bits of max |x| over image n (elems floats per image, nimg images): grid (slices, image groups); `out`
+// zeroed by the caller.
+__global__ void __launch_bounds__(256) cs_image_amax_kernel(const float* x, int64_t elems, int64_t nimg, unsigned* out) {
+  for (int64_t img = blockIdx.y; img < nimg; img += gridDim.y) {
+    const float* xi = x + img * elems;
+    float m = 0.0f;
+    const int64_t n4 = elems >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+      const f32x4 v = *(const f32x4*)(xi + 4 * i);
+      m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+    if (blockIdx.x == 0)
+      for (int64_t i = 4 * n4 + threadIdx.x; i < elems; i += 256) m = fmaxf(m, fabsf(xi[i]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0 && m > 0.0f) atomicMax(out + img, __float_as_uint(m));
+  }
+}
+
 inline unsigned blocks_for(int64_t n) { return (unsigned)((n + 255) / 256); }
 bool g_conv_tail_split = getenv("CSVAE_NO_TAIL_SPLIT") == nullptr;  // measurements without the second launch
 // LDS bytes of cs_conv3x3_halo_split_kernel<CT, PT, NW>: three weight slots, the window, a row of zeros
 // (or, if larger, the epilogue's per-wave transposition regions)
-inline size_t halo3_lds(int ct, int pt, int nw, int win) {
-  const size_t loop = (size_t)3 * ct * 6144 + (size_t)(32 * pt * nw + 2 * (win + 1)) * 192 + 256;
+// terms = 2 (fp16 split): smaller tiles and rows, the rows' scales behind the window; hw > 0: plus the block's table of
+// per-image output maxima at the end (its offset: halo3_lds with hw = 0)
+inline size_t halo3_lds(int ct, int pt, int nw, int win, int terms = 3, int hw = 0) {
+  const size_t nr = (size_t)(32 * pt * nw + 2 * (win + 1));
+  const size_t loop = (size_t)(terms == 2 ? 4 : 3) * ct * 2048 * terms + nr * 64 * terms + 256 + (terms == 2 ? nr * 4 : 0);
   const size_t store = (size_t)nw * 32 * pt * (ct * 128 + 16);
-  return loop > store ? loop : store;
+  const size_t main = ((loop > store ? loop : store) + 15) & ~(size_t)15;
+  return main + (hw > 0 ? 4 * ((size_t)(32 * pt * nw) / hw + 2) : 0);
 }
 
 // exact 3-way bf16 split of a finite float (round to nearest even at every step): v = t0 + t1 + t2
@@ -1516,26 +1697,30 @@ int launch_conv_mfma(const CsConvArgs& a, hipStream_t stream) {
     int dev = 0;
     CS_HIP(hipGetDevice(&dev));
     CS_REQUIRE(dev >= 0 && dev < 64, "device index out of range");
-#define CS_HALO3_LAUNCH_(CT_, PT_, NW_, PH_)                                                                             \
+#define CS_HALO3_LAUNCH_(CT_, PT_, NW_, PH_, TM_)                                                                        \
   do {                                                                                                                   \
     const int NR = 32 * PT_ * NW_ + 2 * (a.win + 1), NP = (NR * 8 + 64 * NW_ - 1) / (64 * NW_);                          \
-    const size_t lds = halo3_lds(CT_, PT_, NW_, a.win);                                                                  \
+    const size_t lds = halo3_lds(CT_, PT_, NW_, a.win, TM_, TM_ == 2 ? a.hout * a.wout : 0);                             \
     CS_REQUIRE(NP <= CS_HALO_NPMAX && lds <= 160 * 1024, "halo window does not fit");                                     \
     static bool attr_set[64] = {};                                                                                       \
     if (!attr_set[dev]) {                                                                                                \
-      CS_HIP(hipFuncSetAttribute((const void*)cs_conv3x3_halo_split_kernel<CT_, PT_, NW_, PH_>,                          \
+      CS_HIP(hipFuncSetAttribute((const void*)cs_conv3x3_halo_split_kernel<CT_, PT_, NW_, PH_, TM_>,                     \
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                               \
       attr_set[dev] = true;                                                                                              \
     }                                                                                                                    \
-    hipLaunchKernelGGL((cs_conv3x3_halo_split_kernel<CT_, PT_, NW_, PH_>),                                               \
+    CsConvArgs al = a;                                                                                                   \
+    al.amax_lds = (int)halo3_lds(CT_, PT_, NW_, a.win, TM_, 0);                                                          \
+    hipLaunchKernelGGL((cs_conv3x3_halo_split_kernel<CT_, PT_, NW_, PH_, TM_>),                                          \
                        dim3((unsigned)((a.npix + 32 * PT_ * NW_ - 1) / (32 * PT_ * NW_)), a.cout_p / (32 * CT_),         \
                             PH_ ? 4 : 1),                                                                                \
-                       dim3(64 * NW_), lds, stream, a, NR, NP);                                                          \
+                       dim3(64 * NW_), lds, stream, al, NR, NP);                                                         \
   } while (0)
-#define CS_HALO3_LAUNCH(CT_, PT_, NW_)                  \
-  do {                                                  \
-    if (phases4) CS_HALO3_LAUNCH_(CT_, PT_, NW_, true); \
-    else CS_HALO3_LAUNCH_(CT_, PT_, NW_, false);        \
+#define CS_HALO3_LAUNCH(CT_, PT_, NW_)                                  \
+  do {                                                                  \
+    if (half && phases4) CS_HALO3_LAUNCH_(CT_, PT_, NW_, true, 2);      \
+    else if (half) CS_HALO3_LAUNCH_(CT_, PT_, NW_, false, 2);           \
+    else if (phases4) CS_HALO3_LAUNCH_(CT_, PT_, NW_, true, 3);         \
+    else CS_HALO3_LAUNCH_(CT_, PT_, NW_, false, 3);                     \
   } while (0)
 #define CS_CONV3_LAUNCH(KERNEL_, LDS_, ...)                                                                             \
   do {                                                                                                                  \
@@ -1565,6 +1750,8 @@ int launch_conv_mfma(const CsConvArgs& a, hipStream_t stream) {
       hipLaunchKernelGGL((cs_conv3x3_halo_resident_kernel<NW_>), dim3((unsigned)grid), dim3(64 * NW_), lds, stream, a, NR,
                          NP, nitems);
     } else if (same3 || phases4) {
+      // fp16 split where the caller supplied its weights and the input's per-image maxima
+      const bool half = a.w3h != nullptr && a.in_amax != nullptr;
       // one 8-wave block per CU (two waves per SIMD); 64-channel layers give a wavefront two pixel tiles so
       // that a weight fragment feeds 12 matrix instructions
       const int big = a.cout_p % 128 == 0 ? 0 : a.cout_p % 64 == 0 ? (halo3_lds(2, 2, 8, a.win) <= 160 * 1024 ? 1 : 2) : 3;
@@ -1601,6 +1788,8 @@ int launch_conv_mfma(const CsConvArgs& a, hipStream_t stream) {
         const int64_t opix = n1 * hw * (a.osc == 2 ? 4 : 1) * a.cout;
         a2.out = a.out + opix;
         if (a.res) a2.res = a.res + opix;
+        if (a.in_amax) a2.in_amax = a.in_amax + n1;
+        if (a.out_amax) a2.out_amax = a.out_amax + n1;
         const int rc = halo(a1, false);
         if (rc != CS_OK) return rc;
         return halo(a2, true);
@@ -1652,8 +1841,26 @@ bool fewout_eligible(const cs_layer_desc& d) {
          d.upsample == 1 && (d.ksize == 3 || d.ksize == 1) && (int64_t)d.ksize * d.ksize * d.cin * 4 * 4 <= 48 * 1024;
 }
 
+// Whether launch_conv runs layer L on the fp16-split halo kernel: the process / network arithmetic asks for it, the
+// layer is a same-size or four-phase upsampled 3x3 convolution of the halo kernel, and its weights are finite.
+bool halo_half_eligible(const CsProgram& p, const CsLayer& L) {
+  const cs_layer_desc& d = L.d;
+  if ((p.arith >= 0 ? p.arith : cs_mlp_arith()) != CS_ARITH_F16X2 || L.wp3_off < 0 || L.wp3h_off < 0) return false;
+  if (d.op != CS_OP_CONV || d.cin % 32 != 0 || d.cout % 32 != 0 || d.out_nchw || d.in_nchw || d.win + 1 > 64) return false;
+  if (L.up_mode == CS_UP_NONE)
+    return d.ksize == 3 && d.stride == 1 && d.pad == 1 && d.upsample == 1 && d.hin == d.hout && d.win == d.wout &&
+           !(d.cin == 32 && d.cout == 32);
+  if (L.up_mode != CS_UP_PHASES) return false;
+  const int64_t st = L.wph3_off[1] - L.wph3_off[0], sth = L.wph3h_off[1] - L.wph3h_off[0];
+  const bool spaced = st > 0 && L.wph3_off[2] - L.wph3_off[0] == 2 * st && L.wph3_off[3] - L.wph3_off[0] == 3 * st && sth > 0 &&
+                      L.wph3h_off[2] - L.wph3h_off[0] == 2 * sth && L.wph3h_off[3] - L.wph3h_off[0] == 3 * sth;
+  return spaced && d.cout % 64 == 0 &&
+         halo3_lds(d.cout % 128 == 0 ? 4 : 2, d.cout % 128 == 0 ? 1 : 2, 8, d.win) <= 160 * 1024;
+}
+
+// in_amax / out_amax: per-image maxima of the source / for the output (fp16 split, see CsConvArgs), or null
 int launch_conv(const CsProgram& p, const CsLayer& L, const float* in, const float* res, float* out, int64_t rows,
-                hipStream_t stream) {
+                hipStream_t stream, const unsigned* in_amax = nullptr, unsigned* out_amax = nullptr) {
   const cs_layer_desc& d = L.d;
   CS_REQUIRE(rows * d.hout * d.wout < ((int64_t)1 << 31), "too many output pixels in one launch");
   CsConvArgs a;
@@ -1667,6 +1874,13 @@ int launch_conv(const CsProgram& p, const CsLayer& L, const float* in, const flo
   a.osc = 1; a.ooh = a.oow = 0; a.rep = 0;
   a.w3_phase_stride = 0;
   a.w3 = nullptr;
+  a.w3h = nullptr;
+  a.w3h_phase_stride = 0;
+  a.wexp[0] = a.wexp[1] = a.wexp[2] = a.wexp[3] = 0;
+  a.in_amax = nullptr;
+  a.out_amax = nullptr;
+  a.amax_lds = 0;
+  const bool half = in_amax != nullptr && halo_half_eligible(p, L);
   const bool same3 = d.ksize == 3 && d.stride == 1 && d.pad == 1 && d.upsample == 1 && d.hin == d.hout && d.win == d.wout;
   if (fewout_eligible(d) && same3 && (size_t)3 * (d.win + 2) * d.cin * 4 <= 48 * 1024) {
     // strips of `sr` rows whose sr + 2 input rows fit 48 KiB of LDS (three blocks per CU)
@@ -1726,6 +1940,12 @@ int launch_conv(const CsProgram& p, const CsLayer& L, const float* in, const flo
   if (L.up_mode == CS_UP_NONE) {
     a.w = p.d_blob + L.wp_off;
     if (split) a.w3 = p.d_blob3 + L.wp3_off;
+    if (split && half) {
+      a.w3h = p.d_blob3h + L.wp3h_off;
+      a.wexp[0] = L.wexp;
+      a.in_amax = in_amax;
+      a.out_amax = out_amax;
+    }
     return launch_conv_mfma(a, stream);
   }
   // upsampled convolutions run on the input's own grid (see CsUpsampleMode)
@@ -1751,6 +1971,13 @@ int launch_conv(const CsProgram& p, const CsLayer& L, const float* in, const flo
       a.w = p.d_blob + L.wph_off[0];
       a.w3 = p.d_blob3 + L.wph3_off[0];
       a.w3_phase_stride = st;
+      if (half) {
+        a.w3h = p.d_blob3h + L.wph3h_off[0];
+        a.w3h_phase_stride = L.wph3h_off[1] - L.wph3h_off[0];
+        for (int ph = 0; ph < 4; ++ph) a.wexp[ph] = L.wphexp[ph];
+        a.in_amax = in_amax;
+        a.out_amax = out_amax;
+      }
       return launch_conv_mfma(a, stream);
     }
   }
@@ -1793,6 +2020,8 @@ void cs_prog_destroy(CsProgram* p) {
   if (!p) return;
   if (p->d_blob) (void)hipFree(p->d_blob);
   if (p->d_blob3) (void)hipFree(p->d_blob3);
+  if (p->d_blob3h) (void)hipFree(p->d_blob3h);
+  if (p->amax_ws) (void)hipFree(p->amax_ws);
   if (p->ws) (void)hipFree(p->ws);
   delete p;
 }
@@ -1810,7 +2039,9 @@ extern "C" int cs_net_create(const cs_layer_desc* layers, int32_t n_layers, cons
   p->buf_elems[CS_NET_BUF_IN] = in_dim;
   p->buf_elems[CS_NET_BUF_OUT] = out_dim;
   std::vector<float> packed;
-  std::vector<uint16_t> packed3;
+  std::vector<uint16_t> packed3, packed3h;
+  int last_writer[CS_NET_NBUF];
+  for (int b = 0; b < CS_NET_NBUF; ++b) last_writer[b] = -1;
   auto fail = [&](const char* msg) {
     delete p;
     return cs_fail(CS_EINVAL, std::string("cs_net_create: ") + msg);
@@ -1862,13 +2093,17 @@ extern "C" int cs_net_create(const cs_layer_desc* layers, int32_t n_layers, cons
     L.d = d;
     L.wp_off = -1;
     L.wp3_off = -1;
+    L.src_layer = d.src == CS_NET_BUF_IN ? -1 : last_writer[d.src];
+    last_writer[d.dst] = i;
     if (mfma_eligible(d) && !fewout_eligible(d)) {
       // Packs weights Wsrc [cout][cin][kk] for the matrix kernels: f32 as [tap][cin_p/32][cout_p][32], zero padded, and
       // the split-bf16 image [tap][cin_p/32][cout_p/32] bricks of [k-step 2][term 3][lane 64] x 8 bf16, the order in
       // which the lanes of a wavefront consume them as the A operand of v_mfma_f32_32x32x16_bf16 (lane l: channel
       // l & 31 of the tile, k = 16*step + 8*(l >> 5) .. + 7).
       const int ncc = (d.cin + 31) / 32, cout_p = (d.cout + 31) & ~31;
-      auto pack = [&](const float* Wsrc, int kk, int64_t* off, int64_t* off3) {
+      // ... and the fp16-split image, the same bricks with two fp16 terms of w 2^kexp, kexp the power of two that
+      // brings the largest weight of the pack into [2^14, 2^15) (*off3h = -1 when a weight is not finite)
+      auto pack = [&](const float* Wsrc, int kk, int64_t* off, int64_t* off3, int64_t* off3h, int* kexp_out) {
         *off = blob_floats + (int64_t)packed.size();
         for (int tap = 0; tap < kk; ++tap)
           for (int cc = 0; cc < ncc; ++cc)
@@ -1895,6 +2130,45 @@ extern "C" int cs_net_create(const cs_layer_desc* layers, int32_t n_layers, cons
               }
               packed3.insert(packed3.end(), brick.begin(), brick.end());
             }
+        bool finite = true;
+        float mx = 0.0f;
+        for (int64_t q = 0; q < (int64_t)d.cout * d.cin * kk; ++q) {
+          if (!std::isfinite(Wsrc[q])) finite = false;
+          mx = std::fmax(mx, std::fabs(Wsrc[q]));
+        }
+        int ex = 0;
+        if (mx > 0.0f && std::isfinite(mx)) (void)std::frexp(mx, &ex);  // mx = m 2^ex, m in [0.5, 1)
+        int kexp = mx > 0.0f ? 15 - ex : 0;
+        kexp = kexp < -100 ? -100 : (kexp > 100 ? 100 : kexp);
+        *kexp_out = kexp;
+        *off3h = -1;
+        if (!finite) return;
+        *off3h = (int64_t)packed3h.size();
+        auto f16_bits = [](float f) {
+          const _Float16 hv = (_Float16)f;  // round to nearest even
+          uint16_t u;
+          std::memcpy(&u, &hv, 2);
+          return u;
+        };
+        for (int tap = 0; tap < kk; ++tap)
+          for (int cc = 0; cc < ncc; ++cc)
+            for (int tile = 0; tile < cout_p / 32; ++tile) {
+              std::vector<uint16_t> brick(2 * 2 * 64 * 8, 0);
+              for (int l = 0; l < 64; ++l) {
+                const int co = tile * 32 + (l & 31);
+                for (int st = 0; st < 2; ++st)
+                  for (int j = 0; j < 8; ++j) {
+                    const int ci = cc * 32 + st * 16 + (l >> 5) * 8 + j;
+                    const float v = co < d.cout && ci < d.cin ? std::ldexp(Wsrc[((int64_t)co * d.cin + ci) * kk + tap], kexp) : 0.0f;
+                    const uint16_t t0 = f16_bits(v);
+                    _Float16 h0;
+                    std::memcpy(&h0, &t0, 2);
+                    brick[((st * 2 + 0) * 64 + l) * 8 + j] = t0;
+                    brick[((st * 2 + 1) * 64 + l) * 8 + j] = f16_bits(v - (float)h0);
+                  }
+              }
+              packed3h.insert(packed3h.end(), brick.begin(), brick.end());
+            }
       };
       const float* W = blob + d.w_off;
       const bool up2 = d.op == CS_OP_CONV && d.upsample == 2 && d.stride == 1 && !d.out_nchw && d.cout % 32 == 0;
@@ -1915,13 +2189,14 @@ extern "C" int cs_net_create(const cs_layer_desc* layers, int32_t n_layers, cons
                       sum += (double)W[cc * 9 + kh * 3 + kw];
                 Wph[cc * 4 + dh * 2 + dw] = (float)sum;
               }
-          pack(Wph.data(), 4, &L.wph_off[ph], &L.wph3_off[ph]);
+          pack(Wph.data(), 4, &L.wph_off[ph], &L.wph3_off[ph], &L.wph3h_off[ph], &L.wphexp[ph]);
         }
         L.wp_off = L.wph_off[0];
         L.wp3_off = L.wph3_off[0];
+        L.wp3h_off = (L.wph3h_off[0] < 0 || L.wph3h_off[1] < 0 || L.wph3h_off[2] < 0 || L.wph3h_off[3] < 0) ? -1 : L.wph3h_off[0];
       } else {
         if (up2 && d.ksize == 1 && d.pad == 0) L.up_mode = CS_UP_REPLICATE;
-        pack(W, d.ksize * d.ksize, &L.wp_off, &L.wp3_off);
+        pack(W, d.ksize * d.ksize, &L.wp_off, &L.wp3_off, &L.wp3h_off, &L.wexp);
       }
     }
     p->layers.push_back(L);
@@ -1936,6 +2211,9 @@ extern "C" int cs_net_create(const cs_layer_desc* layers, int32_t n_layers, cons
   if (e == hipSuccess && !packed3.empty()) e = hipMalloc(&p->d_blob3, packed3.size() * sizeof(uint16_t));
   if (e == hipSuccess && !packed3.empty())
     e = hipMemcpy(p->d_blob3, packed3.data(), packed3.size() * sizeof(uint16_t), hipMemcpyHostToDevice);
+  if (e == hipSuccess && !packed3h.empty()) e = hipMalloc(&p->d_blob3h, packed3h.size() * sizeof(uint16_t));
+  if (e == hipSuccess && !packed3h.empty())
+    e = hipMemcpy(p->d_blob3h, packed3h.data(), packed3h.size() * sizeof(uint16_t), hipMemcpyHostToDevice);
   if (e != hipSuccess) {
     cs_prog_destroy(p);
     return cs_fail(CS_EHIP, std::string("cs_net_create: ") + hipGetErrorString(e));
@@ -1968,9 +2246,12 @@ static int64_t prog_chunk_rows(const CsProgram* p, int64_t rows, int64_t* per_ro
 static int prog_grow_workspace(CsProgram* p, int64_t chunk, int64_t per_row) {
   if (chunk <= p->ws_rows) return CS_OK;
   if (p->ws) CS_HIP(hipFree(p->ws));  // waits for the work that still uses it
+  if (p->amax_ws) CS_HIP(hipFree(p->amax_ws));
   p->ws = nullptr;
+  p->amax_ws = nullptr;
   p->ws_rows = 0;
   CS_HIP(hipMalloc(&p->ws, (size_t)chunk * per_row * sizeof(float)));
+  CS_HIP(hipMalloc(&p->amax_ws, (p->layers.size() + 1) * (size_t)chunk * sizeof(unsigned)));
   p->ws_rows = chunk;
   return CS_OK;
 }
@@ -2026,13 +2307,38 @@ int cs_prog_launch(const CsMlpArgs& a, hipStream_t stream) {
       input = buf[CS_NET_BUF_IN];
     }
     float* raw = a.mode == CS_MLP_RAW ? a.out + row0 * p->out_dim : buf[CS_NET_BUF_OUT];
-    for (const CsLayer& L : p->layers) {
+    // fp16 split: slot i of the table of per-image maxima belongs to the output of layer i (written by the halo
+    // kernel's epilogue), the last slot to the network input; a source whose producer did not write its slot gets a
+    // reduction pass of its own
+    const size_t nlay = p->layers.size();
+    std::vector<char> have(nlay + 1, 0);
+    bool any_half = false;
+    for (const CsLayer& L : p->layers) any_half = any_half || halo_half_eligible(*p, L);
+    if (any_half) CS_HIP(hipMemsetAsync(p->amax_ws, 0, (nlay + 1) * (size_t)p->ws_rows * sizeof(unsigned), stream));
+    for (size_t li = 0; li < nlay; ++li) {
+      const CsLayer& L = p->layers[li];
       const cs_layer_desc& d = L.d;
       const float* src = d.src == CS_NET_BUF_IN ? input : buf[d.src];
       const float* res = d.res < 0 ? nullptr : (d.res == CS_NET_BUF_IN ? input : buf[d.res]);
       float* dst = d.dst == CS_NET_BUF_OUT ? raw : buf[d.dst];
       if (d.op == CS_OP_CONV || d.op == CS_OP_LINEAR) {
-        if (int rc = launch_conv(*p, L, src, res, dst, rows, stream)) return rc;
+        const unsigned* in_amax = nullptr;
+        unsigned* out_amax = nullptr;
+        if (any_half && halo_half_eligible(*p, L)) {
+          const size_t slot = L.src_layer < 0 ? nlay : (size_t)L.src_layer;
+          unsigned* tab = p->amax_ws + slot * (size_t)p->ws_rows;
+          if (!have[slot]) {
+            const int64_t elems = (int64_t)d.cin * d.hin * d.win;
+            const unsigned gx = (unsigned)std::min<int64_t>((elems / 4 + 255) / 256 > 0 ? (elems / 4 + 255) / 256 : 1, 16);
+            hipLaunchKernelGGL(cs_image_amax_kernel, dim3(gx, (unsigned)std::min<int64_t>(rows, 32768)), dim3(256), 0, stream, src,
+                               elems, rows, tab);
+            have[slot] = 1;
+          }
+          in_amax = tab;
+          out_amax = p->amax_ws + li * (size_t)p->ws_rows;
+          have[li] = 1;
+        }
+        if (int rc = launch_conv(*p, L, src, res, dst, rows, stream, in_amax, out_amax)) return rc;
       } else if (d.op == CS_OP_LAYERNORM) {
         hipLaunchKernelGGL(cs_layernorm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, src, dst, rows,
                            d.cin, p->d_blob + d.w_off, p->d_blob + d.b_off, d.relu);

@@ -40,7 +40,7 @@ def main():
         net.forward(x)
     torch.cuda.synchronize()
     L = _lib.lib()
-    px = 512 if c == 64 else 256
+    px = int(os.environ.get("CS_STAMP_PX", 512 if c == 64 else 256))
     nb = min(8192, (rows * hw * hw + px - 1) // px)
     buf = (C.c_ulonglong * (8 * nb))()
     L.cs_debug_conv_stamps.argtypes = [C.c_void_p, C.c_int]

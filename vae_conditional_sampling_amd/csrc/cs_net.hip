@@ -607,18 +607,21 @@ __global__ void __launch_bounds__(64 * NW) cs_conv3x3_halo_split_kernel(const Cs
   }
   if (tid < 16) *(lds_u32x4n*)(s_halo + zero_off + tid * 16) = u32x4n{0u, 0u, 0u, 0u};
   const int hw = H * W;
+  // position of the block's first pixel inside its image: one 64-bit division per workgroup (uniform), 32-bit
+  // arithmetic per lane (a block spans fewer than 2^10 pixels)
+  const int rem0 = (int)cs_scalar_u32((unsigned)(p0 % hw));
+  const int64_t img0 = (p0 - rem0) / hw;  // image of the block's first pixel (uniform)
   if (TERMS == 2) {
-    // the power of two of every window row's image; rows outside the launch hold zeros under any scale
+    // the power of two of every window row's image; rows outside the launch hold zeros under any scale.  Window row r
+    // is pixel rem0 - (W + 1) + r counted from the first pixel of image img0 (W + 1 <= 2 hw: at most two images back).
     for (int r = tid; r < NR; r += NTHR) {
       const int64_t q = p0 - (W + 1) + r;
-      s_g[r] = (q >= 0 && q < a.npix) ? conv_image_scale(a.in_amax[q / hw]) : 1.0f;
+      const int rel = (int)((unsigned)(rem0 - (W + 1) + r + 2 * hw) / (unsigned)hw) - 2;
+      s_g[r] = (q >= 0 && q < a.npix) ? conv_image_scale(a.in_amax[img0 + rel]) : 1.0f;
     }
     if (a.out_amax)
       for (int r = tid; r < (PX * NW) / hw + 2; r += NTHR) s_amax[r] = 0u;
   }
-  // position of the block's first pixel inside its image: one 64-bit division per workgroup (uniform), 32-bit
-  // arithmetic per lane (a block spans fewer than 2^10 pixels)
-  const int rem0 = (int)cs_scalar_u32((unsigned)(p0 % hw));
 #pragma unroll
   for (int p = 0; p < PT; ++p) {
     row0[p] = wave * PX + p * 32 + l31;
@@ -788,7 +791,6 @@ __global__ void __launch_bounds__(64 * NW) cs_conv3x3_halo_split_kernel(const Cs
     if (amax) {
       // the block's table of per-image maxima joins the launch's (image of the block's first pixel: (p0 - rem0) / hw)
       __syncthreads();
-      const int64_t img0 = (p0 - rem0) / hw;
       for (int r = tid; r < (PX * NW) / hw + 2; r += NTHR) {
         const unsigned v = s_amax[r];
         if (v != 0u) atomicMax(a.out_amax + img0 + r, v);

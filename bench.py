@@ -423,14 +423,22 @@ def extra_legs(args, arith, dev):
         # shortcuts move more bytes than they compute): price every layer at the larger of its matrix time at the
         # arithmetic's ceiling and its memory time at the HBM peak, and report the iteration against that sum.
         from vae_conditional_sampling_amd import _lib
-        ideal = (_lib.layerwise_ideal_seconds(model.var_latent_network._program().layers, enc_rows, peak_of(arith) * 1e12) +
-                 _lib.layerwise_ideal_seconds(model.generator_network._program().layers, dec_rows, peak_of(arith) * 1e12))
+        half = F16X2_PEAK_TFLOPS * 1e12 if lib_arith == "f16x2" else None
+        ideal = (_lib.layerwise_ideal_seconds(model.var_latent_network._program().layers, enc_rows, peak_of(arith) * 1e12,
+                                              fp16_split_flops_per_s=half) +
+                 _lib.layerwise_ideal_seconds(model.generator_network._program().layers, dec_rows, peak_of(arith) * 1e12,
+                                              fp16_split_flops_per_s=half))
         leg["layerwise_roofline"] = {"ideal_ms": ideal * 1e3, "frac": ideal * 1e3 / leg["ms_per_step"],
-                                     "what": "sum over the layers of both networks of max(algorithmic FLOPs / matrix ceiling, "
-                                             "algorithmic activation bytes / 8 TB/s), divided by the measured iteration"}
+                                     "what": "sum over the layers of both networks of max(algorithmic FLOPs / the layer's matrix "
+                                             "ceiling, algorithmic activation bytes / 8 TB/s), divided by the measured iteration"}
+        leg["arithmetic"] = ("3x3 halo layers: fp16 split (2 terms, ceiling %.1f); other matrix layers: bf16 split (3 terms, "
+                             "ceiling %.1f); roofline.frac is against the bf16-split ceiling" % (F16X2_PEAK_TFLOPS, SPLIT_PEAK_TFLOPS)
+                             if half else arith)
         return leg
 
-    # layer programs (the convolutional networks) run the bf16 split under every setting but exact f32
+    # layer programs (the convolutional networks): the 3x3 halo layers follow the fp16 split, every other matrix layer
+    # runs the bf16 split under every setting but exact f32; the legs' roofline.frac is against the bf16-split ceiling
+    lib_arith = arith
     arith = "f32" if arith == "f32" else "bf16x3"
     fe, fd = CONV_FLOPS["omniglot"]
     m = conv_vae("omniglot", dev)

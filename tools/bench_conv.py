@@ -60,11 +60,15 @@ def main():
         ms = (time.perf_counter() - t0) / n * 1e3
         from vae_conditional_sampling_amd import _lib
         arith = _lib.get_mlp_arith()
-        peak = 157.3 if arith == "f32" else 2500.0 / 6   # algorithmic TFLOP/s: exact f32, or dense bf16 peak / 6 term products
-        ideal = _lib.layerwise_ideal_seconds(net._program().layers, rows, peak * 1e12) * 1e3
+        # algorithmic TFLOP/s ceilings: exact f32; dense bf16 peak / 6 term products (3-term bf16 split); under the
+        # fp16 split the 3x3 halo layers run 3 term products (dense fp16 peak / 3), the other layers keep the bf16 split
+        peak = 157.3 if arith == "f32" else 2500.0 / 6
+        half = 2500.0 / 3 * 1e12 if arith == "f16x2" else None
+        ideal = _lib.layerwise_ideal_seconds(net._program().layers, rows, peak * 1e12, fp16_split_flops_per_s=half) * 1e3
+        mix = "" if half is None else " (fp16-split halo layers at 833.3)"
         print(f"{name} {label}: rows={rows} {fl / 1e6:.1f} MFLOP/img  {ms:.3f} ms  {fl * rows / ms / 1e9:.1f} algorithmic TFLOP/s "
-              f"({fl * rows / ms / 1e9 / peak * 100:.1f}% of the {arith} ceiling {peak:.1f}); layer-wise roofline "
-              f"(each layer at the larger of its matrix time and its HBM time at 8 TB/s) {ideal:.3f} ms = {ideal / ms * 100:.1f}%")
+              f"({fl * rows / ms / 1e9 / peak * 100:.1f}% of the 3-term bf16 split ceiling {peak:.1f}; arithmetic {arith}); layer-wise "
+              f"roofline (each layer at the larger of its matrix time{mix} and its HBM time at 8 TB/s) {ideal:.3f} ms = {ideal / ms * 100:.1f}%")
 
 
 if __name__ == "__main__":

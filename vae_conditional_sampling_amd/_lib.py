@@ -79,9 +79,28 @@ def program_layer_costs(layers):
     return out
 
 
-def layerwise_ideal_seconds(layers, rows, flops_per_s, bytes_per_s=8.0e12):
-    """Sum over the layers of max(matrix time, memory time) for `rows` rows."""
-    return sum(max(f * rows / flops_per_s, b * rows / bytes_per_s) for f, b in program_layer_costs(layers))
+def layer_runs_fp16_split(L):
+    """Whether a layer of a layer program runs on the fp16-split (2-term) halo kernel when that arithmetic is selected
+    (halo_half_eligible in csrc/cs_net.hip): same-size 3x3 convolutions of 32-multiple channel counts other than
+    32 -> 32, and 2x-upsampled 3x3 convolutions to 64-multiple channel counts; every other matrix layer keeps the
+    3-term bf16 split."""
+    if L.op != CS_OP_CONV or L.cin % 32 or L.cout % 32 or L.out_nchw or L.in_nchw or L.win + 1 > 64 or L.ksize != 3:
+        return False
+    if L.stride != 1 or L.pad != 1:
+        return False
+    if L.upsample == 1:
+        return L.hin == L.hout and L.win == L.wout and not (L.cin == 32 and L.cout == 32)
+    return L.upsample == 2 and L.cout % 64 == 0
+
+
+def layerwise_ideal_seconds(layers, rows, flops_per_s, bytes_per_s=8.0e12, fp16_split_flops_per_s=None):
+    """Sum over the layers of max(matrix time, memory time) for `rows` rows.  fp16_split_flops_per_s: the matrix
+    ceiling of the layers that run the fp16 split (layer_runs_fp16_split), when that arithmetic is selected."""
+    total = 0.0
+    for L, (f, b) in zip(layers, program_layer_costs(layers)):
+        peak = fp16_split_flops_per_s if fp16_split_flops_per_s and layer_runs_fp16_split(L) else flops_per_s
+        total += max(f * rows / peak, b * rows / bytes_per_s)
+    return total
 
 
 class cs_rng(C.Structure):

@@ -770,17 +770,17 @@ __global__ void __launch_bounds__(64 * NW) cs_conv3x3_halo_split_kernel(const Cs
   CS_CONV_STAMP(2, __builtin_amdgcn_s_memrealtime());
   CS_CONV_STAMP(5, __builtin_amdgcn_s_memtime());
   if constexpr (TERMS == 2) {
-    // back to true values: the lane's pixel of tile p is window row row0[p] + W + 1; 1 / (its image's power of two) and
-    // 1 / (the weights' power of two), both exact
+    // back to true values: the lane's pixel of tile p is window row row0[p] + W + 1
     const int wexp = PHASE ? a.wexp[blockIdx.z] : a.wexp[0];
-    const float winv = __uint_as_float((unsigned)(127 - wexp) << 23);
 #pragma unroll
     for (int p = 0; p < PT; ++p) {
-      const float ginv = __uint_as_float((254u << 23) - __float_as_uint(s_g[row0[p] + W + 1])) * winv;
+      // the image's scale is 2^-e: scale back by 2^(e - wexp) in one exact step (the two powers of two multiplied
+      // into one float could leave its range)
+      const int e = 127 - (int)(__float_as_uint(s_g[row0[p] + W + 1]) >> 23);
 #pragma unroll
       for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[p][ct][r] *= ginv;
+        for (int r = 0; r < 16; ++r) acc[p][ct][r] = __builtin_ldexpf(acc[p][ct][r], e - wexp);
     }
   }
   if ((a.cout & 31) == 0 && !a.out_nchw) {

@@ -80,17 +80,16 @@ def program_layer_costs(layers):
 
 
 def layer_runs_fp16_split(L):
-    """Whether a layer of a layer program runs on the fp16-split (2-term) halo kernel when that arithmetic is selected
-    (halo_half_eligible in csrc/cs_net.hip): same-size 3x3 convolutions of 32-multiple channel counts other than
-    32 -> 32, and 2x-upsampled 3x3 convolutions to 64-multiple channel counts; every other matrix layer keeps the
-    3-term bf16 split."""
-    if L.op != CS_OP_CONV or L.cin % 32 or L.cout % 32 or L.out_nchw or L.in_nchw or L.win + 1 > 64 or L.ksize != 3:
+    """Whether a layer of a layer program runs the fp16-split (2-term) arithmetic when it is selected
+    (layer_half_kind in csrc/cs_net.hip): the convolutions of the matrix kernels (16 input channels and up, NHWC
+    input) except the 32 -> 32 channel same-size 3x3 layers of the weight-resident kernel and the convolutions to at
+    most 4 channels; linear layers and those keep the 3-term bf16 split."""
+    if L.op != CS_OP_CONV or L.in_nchw or L.cin < 16:
         return False
-    if L.stride != 1 or L.pad != 1:
+    if L.cout <= 4 and L.cin in (32, 64, 128, 256) and L.upsample == 1 and L.ksize in (1, 3):
         return False
-    if L.upsample == 1:
-        return L.hin == L.hout and L.win == L.wout and not (L.cin == 32 and L.cout == 32)
-    return L.upsample == 2 and L.cout % 64 == 0
+    same3 = L.ksize == 3 and L.stride == 1 and L.pad == 1 and L.upsample == 1 and L.hin == L.hout and L.win == L.wout
+    return not (same3 and L.cin == 32 and L.cout == 32 and not L.out_nchw)
 
 
 def layerwise_ideal_seconds(layers, rows, flops_per_s, bytes_per_s=8.0e12, fp16_split_flops_per_s=None):

@@ -987,9 +987,12 @@ __global__ void __launch_bounds__(64 * NW) cs_conv3x3_halo_resident_kernel(const
 // the activation tile of a chunk is split into its three bf16 terms as it is staged, the weight tile
 // comes pre-split in the brick order of cs_conv3x3_halo_split_kernel; the activation rows have its row layout and
 // slot swizzle.
-template <int CT>
+// TERMS = 2: the fp16 split of the halo kernel (two fp16 terms, three products, operands of image n scaled by the power
+// of two from in_amax[n]: a source pixel belongs to its output pixel's image; 128-byte rows with that kernel's slot
+// swizzle; weights from a.w3h with exponent a.wexp[0]).
+template <int CT, int TERMS = 3>
 __global__ void __launch_bounds__(256) cs_conv_mfma_split_kernel(const CsConvArgs a) {
-  constexpr int ROWB = 192, W_B = CT * 32 * ROWB;
+  constexpr int ROWB = 64 * TERMS, W_B = CT * 32 * ROWB;
   constexpr int NPC = (W_B / 16 + 255) / 256;
   extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
   unsigned char* s_pix = s_raw;             // [128][ROWB]
@@ -1005,6 +1008,7 @@ __global__ void __launch_bounds__(256) cs_conv_mfma_split_kernel(const CsConvArg
   int ih0[4], iw0[4];
   int64_t base[4];
   bool pv[4];
+  float gsc[4];  // TERMS = 2: the power of two of the row's image
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
     const int64_t gp = (int64_t)blockIdx.x * 128 + (tid >> 3) + 32 * p;
@@ -1017,8 +1021,9 @@ __global__ void __launch_bounds__(256) cs_conv_mfma_split_kernel(const CsConvArg
     ih0[p] = oh * a.stride - a.pad_h;
     iw0[p] = ow * a.stride - a.pad_w;
     base[p] = n * a.hin * a.win;
+    gsc[p] = (TERMS == 2 && pv[p]) ? conv_image_scale(a.in_amax[n]) : 1.0f;
   }
-  const unsigned char* wblk = (const unsigned char*)a.w3 + (int64_t)blockIdx.y * W_B;
+  const unsigned char* wblk = (TERMS == 2 ? (const unsigned char*)a.w3h : (const unsigned char*)a.w3) + (int64_t)blockIdx.y * W_B;
 
   f32x16 acc[CT];
 #pragma unroll
@@ -1074,6 +1079,17 @@ __global__ void __launch_bounds__(256) cs_conv_mfma_split_kernel(const CsConvArg
     for (int p = 0; p < 4; ++p) {
       const int row = (tid >> 3) + 32 * p;
       const f32x4 v = rp[p];
+      if constexpr (TERMS == 2) {
+        const float g = gsc[p];
+        const unsigned a0 = conv_mix_pk_f16(v.x, v.y, g), b0 = conv_mix_pk_f16(v.z, v.w, g);
+        const float r0 = conv_mix_rem_lo(v.x, g, a0), r1 = conv_mix_rem_hi(v.y, g, a0);
+        const float r2 = conv_mix_rem_lo(v.z, g, b0), r3 = conv_mix_rem_hi(v.w, g, b0);
+        const unsigned a1 = conv_cvt_pk_f16(r0, r1), b1 = conv_cvt_pk_f16(r2, r3);
+        const unsigned o = (unsigned)row * ROWB + ((unsigned)((c4 >> 1) ^ ((row >> 1) & 7)) << 4) + ((unsigned)(c4 & 1) << 3);
+        *(u32x2n*)(s_pix + o) = u32x2n{a0, b0};
+        *(u32x2n*)(s_pix + (o ^ 64u)) = u32x2n{a1, b1};
+        continue;
+      }
       const unsigned a0 = conv_cvt_pk(v.x, v.y), b0 = conv_cvt_pk(v.z, v.w);
       const float r0 = v.x - __uint_as_float(a0 << 16), r1 = v.y - __uint_as_float(a0 & 0xffff0000u);
       const float r2 = v.z - __uint_as_float(b0 << 16), r3 = v.w - __uint_as_float(b0 & 0xffff0000u);
@@ -1095,7 +1111,7 @@ __global__ void __launch_bounds__(256) cs_conv_mfma_split_kernel(const CsConvArg
   fetch(0);
   const int rowB = wave * 32 + l31;
   const unsigned char* bp = s_pix + rowB * ROWB;
-  const int swz = (l31 >> 2) & 3;  // rowB and the weight rows differ from l31 by multiples of 32
+  const int swz = TERMS == 2 ? (l31 >> 1) & 7 : (l31 >> 2) & 3;  // rowB and the weight rows differ from l31 by multiples of 32
   const unsigned char* ap = s_w + lane * 16;  // weight bricks: [channel tile][k-step][term][lane] x 16 bytes
   for (int t = 0; t < nchunks; ++t) {
     __syncthreads();  // previous chunk's reads are done
@@ -1105,27 +1121,43 @@ __global__ void __launch_bounds__(256) cs_conv_mfma_split_kernel(const CsConvArg
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       const int off = ((2 * s + h) ^ swz) << 4;
-      u32x4n b[3];
+      u32x4n b[TERMS];
 #pragma unroll
-      for (int tm = 0; tm < 3; ++tm) b[tm] = *(const u32x4n*)(bp + tm * 64 + off);
+      for (int tm = 0; tm < TERMS; ++tm) b[tm] = *(const u32x4n*)(bp + (TERMS == 2 ? off ^ (tm << 6) : tm * 64 + off));
 #pragma unroll
       for (int ct = 0; ct < CT; ++ct) {
-        u32x4n w[3];
+        u32x4n w[TERMS];
 #pragma unroll
-        for (int tm = 0; tm < 3; ++tm) w[tm] = *(const u32x4n*)(ap + ((ct * 2 + s) * 3 + tm) * 1024);
+        for (int tm = 0; tm < TERMS; ++tm) w[tm] = *(const u32x4n*)(ap + ((ct * 2 + s) * TERMS + tm) * 1024);
+        if constexpr (TERMS == 2) {
+          CS_CONV_MFMA32H(w[0], b[0], acc[ct]);
+          CS_CONV_MFMA32H(w[0], b[1], acc[ct]);
+          CS_CONV_MFMA32H(w[1], b[0], acc[ct]);
+          continue;
+        }
 #define CS_CONV_MFMA(A_, B_) \
   acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8n, A_), __builtin_bit_cast(bf16x8n, B_), acc[ct], 0, 0, 0)
         CS_CONV_MFMA(w[0], b[0]);
         CS_CONV_MFMA(w[0], b[1]);
         CS_CONV_MFMA(w[1], b[0]);
-        CS_CONV_MFMA(w[0], b[2]);
+        CS_CONV_MFMA(w[0], b[TERMS - 1]);
         CS_CONV_MFMA(w[1], b[1]);
-        CS_CONV_MFMA(w[2], b[0]);
+        CS_CONV_MFMA(w[TERMS - 1], b[0]);
 #undef CS_CONV_MFMA
       }
     }
   }
   cs_mfma_drain();
+  if constexpr (TERMS == 2) {
+    // back to true values, in one exact step: 2^(e - wexp), 2^-e the scale of the lane's pixel's image
+    const int64_t gp = (int64_t)blockIdx.x * 128 + wave * 32 + l31;
+    const float g = gp < a.npix ? conv_image_scale(a.in_amax[gp / (a.hout * a.wout)]) : 1.0f;
+    const int e = 127 - (int)(__float_as_uint(g) >> 23) - a.wexp[0];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[ct][r] = __builtin_ldexpf(acc[ct][r], e);
+  }
   conv_store<CT>(a, acc, (int64_t)blockIdx.x * 128 + wave * 32 + l31, blockIdx.y * (CT * 32), h);
 }
 
@@ -1797,6 +1829,17 @@ int launch_conv_mfma(const CsConvArgs& a, hipStream_t stream) {
         return halo(a2, true);
       }
       return halo(a, false);
+    } else if (a.w3h != nullptr && a.in_amax != nullptr) {  // generic kernel, fp16 split
+      if (a.cout_p % 128 == 0) {
+        constexpr int CT_ = 4;
+        CS_CONV3_LAUNCH((cs_conv_mfma_split_kernel<CT_, 2>), (size_t)(128 + CT_ * 32) * 128);
+      } else if (a.cout_p % 64 == 0) {
+        constexpr int CT_ = 2;
+        CS_CONV3_LAUNCH((cs_conv_mfma_split_kernel<CT_, 2>), (size_t)(128 + CT_ * 32) * 128);
+      } else {
+        constexpr int CT_ = 1;
+        CS_CONV3_LAUNCH((cs_conv_mfma_split_kernel<CT_, 2>), (size_t)(128 + CT_ * 32) * 128);
+      }
     } else if (a.cout_p % 128 == 0) {
       constexpr int CT_ = 4;
       CS_CONV3_LAUNCH((cs_conv_mfma_split_kernel<CT_>), (size_t)(128 + CT_ * 32) * 192);
@@ -1843,21 +1886,30 @@ bool fewout_eligible(const cs_layer_desc& d) {
          d.upsample == 1 && (d.ksize == 3 || d.ksize == 1) && (int64_t)d.ksize * d.ksize * d.cin * 4 * 4 <= 48 * 1024;
 }
 
-// Whether launch_conv runs layer L on the fp16-split halo kernel: the process / network arithmetic asks for it, the
-// layer is a same-size or four-phase upsampled 3x3 convolution of the halo kernel, and its weights are finite.
-bool halo_half_eligible(const CsProgram& p, const CsLayer& L) {
+// How launch_conv runs layer L under the fp16-split arithmetic: 0 = not at all (another arithmetic is selected, a
+// weight is not finite, or the layer runs on a kernel without that arithmetic: the weight-resident 32 -> 32 channel
+// kernel, the few-channel and direct kernels, linear layers), 1 = on the halo kernel (same-size and four-phase
+// upsampled 3x3 convolutions; its epilogue leaves the per-image maxima of the output), 2 = on the generic kernel.
+int layer_half_kind(const CsProgram& p, const CsLayer& L) {
   const cs_layer_desc& d = L.d;
-  if ((p.arith >= 0 ? p.arith : cs_mlp_arith()) != CS_ARITH_F16X2 || L.wp3_off < 0 || L.wp3h_off < 0) return false;
-  if (d.op != CS_OP_CONV || d.cin % 32 != 0 || d.cout % 32 != 0 || d.out_nchw || d.in_nchw || d.win + 1 > 64) return false;
-  if (L.up_mode == CS_UP_NONE)
-    return d.ksize == 3 && d.stride == 1 && d.pad == 1 && d.upsample == 1 && d.hin == d.hout && d.win == d.wout &&
-           !(d.cin == 32 && d.cout == 32);
-  if (L.up_mode != CS_UP_PHASES) return false;
+  if ((p.arith >= 0 ? p.arith : cs_mlp_arith()) != CS_ARITH_F16X2 || L.wp3_off < 0 || L.wp3h_off < 0) return 0;
+  if (d.op != CS_OP_CONV || d.in_nchw) return 0;
+  const bool halo_ok = d.cin % 32 == 0 && d.cout % 32 == 0 && !d.out_nchw && d.win + 1 <= 64;
+  if (L.up_mode == CS_UP_NONE) {
+    const bool same3 = d.ksize == 3 && d.stride == 1 && d.pad == 1 && d.upsample == 1 && d.hin == d.hout && d.win == d.wout;
+    if (same3 && d.cin == 32 && d.cout == 32 && !d.out_nchw) return 0;  // weight-resident kernel
+    return same3 && halo_ok ? 1 : 2;
+  }
+  if (L.up_mode == CS_UP_REPLICATE) return 2;
+  for (int ph = 0; ph < 4; ++ph)
+    if (L.wph3h_off[ph] < 0) return 0;
   const int64_t st = L.wph3_off[1] - L.wph3_off[0], sth = L.wph3h_off[1] - L.wph3h_off[0];
   const bool spaced = st > 0 && L.wph3_off[2] - L.wph3_off[0] == 2 * st && L.wph3_off[3] - L.wph3_off[0] == 3 * st && sth > 0 &&
                       L.wph3h_off[2] - L.wph3h_off[0] == 2 * sth && L.wph3h_off[3] - L.wph3h_off[0] == 3 * sth;
-  return spaced && d.cout % 64 == 0 &&
-         halo3_lds(d.cout % 128 == 0 ? 4 : 2, d.cout % 128 == 0 ? 1 : 2, 8, d.win) <= 160 * 1024;
+  return (halo_ok && spaced && d.cout % 64 == 0 &&
+          halo3_lds(d.cout % 128 == 0 ? 4 : 2, d.cout % 128 == 0 ? 1 : 2, 8, d.win) <= 160 * 1024)
+             ? 1
+             : 2;
 }
 
 // in_amax / out_amax: per-image maxima of the source / for the output (fp16 split, see CsConvArgs), or null
@@ -1882,7 +1934,8 @@ int launch_conv(const CsProgram& p, const CsLayer& L, const float* in, const flo
   a.in_amax = nullptr;
   a.out_amax = nullptr;
   a.amax_lds = 0;
-  const bool half = in_amax != nullptr && halo_half_eligible(p, L);
+  const int half_kind = in_amax != nullptr ? layer_half_kind(p, L) : 0;
+  const bool half = half_kind == 1;
   const bool same3 = d.ksize == 3 && d.stride == 1 && d.pad == 1 && d.upsample == 1 && d.hin == d.hout && d.win == d.wout;
   if (fewout_eligible(d) && same3 && (size_t)3 * (d.win + 2) * d.cin * 4 <= 48 * 1024) {
     // strips of `sr` rows whose sr + 2 input rows fit 48 KiB of LDS (three blocks per CU)
@@ -1942,11 +1995,11 @@ int launch_conv(const CsProgram& p, const CsLayer& L, const float* in, const flo
   if (L.up_mode == CS_UP_NONE) {
     a.w = p.d_blob + L.wp_off;
     if (split) a.w3 = p.d_blob3 + L.wp3_off;
-    if (split && half) {
+    if (split && half_kind != 0) {
       a.w3h = p.d_blob3h + L.wp3h_off;
       a.wexp[0] = L.wexp;
       a.in_amax = in_amax;
-      a.out_amax = out_amax;
+      if (half) a.out_amax = out_amax;
     }
     return launch_conv_mfma(a, stream);
   }
@@ -1959,6 +2012,11 @@ int launch_conv(const CsProgram& p, const CsLayer& L, const float* in, const flo
     a.rep = 1;
     a.w = p.d_blob + L.wp_off;
     if (split) a.w3 = p.d_blob3 + L.wp3_off;
+    if (split && half_kind == 2) {
+      a.w3h = p.d_blob3h + L.wp3h_off;
+      a.wexp[0] = L.wexp;
+      a.in_amax = in_amax;
+    }
     return launch_conv_mfma(a, stream);
   }
   a.ksize = 2;
@@ -1988,6 +2046,11 @@ int launch_conv(const CsProgram& p, const CsLayer& L, const float* in, const flo
     a.pad_h = 1 - a.ooh; a.pad_w = 1 - a.oow;
     a.w = p.d_blob + L.wph_off[ph];
     a.w3 = split ? p.d_blob3 + L.wph3_off[ph] : nullptr;
+    if (split && half_kind == 2) {
+      a.w3h = p.d_blob3h + L.wph3h_off[ph];
+      a.wexp[0] = L.wphexp[ph];
+      a.in_amax = in_amax;
+    }
     const int rc = launch_conv_mfma(a, stream);
     if (rc != CS_OK) return rc;
   }
@@ -2315,7 +2378,7 @@ int cs_prog_launch(const CsMlpArgs& a, hipStream_t stream) {
     const size_t nlay = p->layers.size();
     std::vector<char> have(nlay + 1, 0);
     bool any_half = false;
-    for (const CsLayer& L : p->layers) any_half = any_half || halo_half_eligible(*p, L);
+    for (const CsLayer& L : p->layers) any_half = any_half || layer_half_kind(*p, L) != 0;
     if (any_half) CS_HIP(hipMemsetAsync(p->amax_ws, 0, (nlay + 1) * (size_t)p->ws_rows * sizeof(unsigned), stream));
     for (size_t li = 0; li < nlay; ++li) {
       const CsLayer& L = p->layers[li];
@@ -2326,7 +2389,8 @@ int cs_prog_launch(const CsMlpArgs& a, hipStream_t stream) {
       if (d.op == CS_OP_CONV || d.op == CS_OP_LINEAR) {
         const unsigned* in_amax = nullptr;
         unsigned* out_amax = nullptr;
-        if (any_half && halo_half_eligible(*p, L)) {
+        const int kind = any_half ? layer_half_kind(*p, L) : 0;
+        if (kind != 0) {
           const size_t slot = L.src_layer < 0 ? nlay : (size_t)L.src_layer;
           unsigned* tab = p->amax_ws + slot * (size_t)p->ws_rows;
           if (!have[slot]) {
@@ -2337,8 +2401,10 @@ int cs_prog_launch(const CsMlpArgs& a, hipStream_t stream) {
             have[slot] = 1;
           }
           in_amax = tab;
-          out_amax = p->amax_ws + li * (size_t)p->ws_rows;
-          have[li] = 1;
+          if (kind == 1) {
+            out_amax = p->amax_ws + li * (size_t)p->ws_rows;
+            have[li] = 1;
+          }
         }
         if (int rc = launch_conv(*p, L, src, res, dst, rows, stream, in_amax, out_amax)) return rc;
       } else if (d.op == CS_OP_LAYERNORM) {

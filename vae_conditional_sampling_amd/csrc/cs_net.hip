@@ -68,8 +68,11 @@ __device__ __forceinline__ int64_t conv_out_pix(const CsConvArgs& a, int64_t gp,
 // holds channels co0 + 32ct + 8q + 4h + 0..3.  Bias, residual and ReLU are applied here.
 template <int CT>
 __device__ __forceinline__ void conv_store(const CsConvArgs& a, const f32x16 (&acc)[CT], int64_t gp, int co0, int h) {
-  if (gp >= a.npix) return;
-  if ((a.cout & 31) == 0 && !a.out_nchw) {
+  // out_amax (NHWC outputs of 32-multiple channel counts only): the largest magnitude the lane stores, merged over
+  // the wave's lanes of the same image (consecutive lanes hold consecutive pixels) before one atomic per image
+  float amx = 0.0f;
+  const bool want_amax = a.out_amax != nullptr && (a.cout & 31) == 0 && !a.out_nchw;
+  if (gp < a.npix && (a.cout & 31) == 0 && !a.out_nchw) {
     for (int ph = 0; ph < (a.rep ? 4 : 1); ++ph) {
       const int64_t op = a.rep ? conv_out_pix(a, gp, ph >> 1, ph & 1) : conv_out_pix(a, gp, a.ooh, a.oow);
       float* orow = a.out + op * a.cout + co0;
@@ -87,9 +90,10 @@ __device__ __forceinline__ void conv_store(const CsConvArgs& a, const f32x16 (&a
             for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.0f);
           }
           *(f32x4*)(orow + c) = v;
+          if (want_amax) amx = fmaxf(fmaxf(amx, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
         }
     }
-  } else {
+  } else if (gp < a.npix) {
     // scalar path: channel counts that are not multiples of 32, channel-major outputs (osc = 1 only)
     const int hw = a.hout * a.wout;
     const int64_t n = gp / hw;
@@ -108,6 +112,19 @@ __device__ __forceinline__ void conv_store(const CsConvArgs& a, const f32x16 (&a
           else a.out[gp * a.cout + co] = v;
         }
       }
+  }
+  if (want_amax) {  // every lane of the wave arrives here
+    const int lane = (int)(threadIdx.x & 63);
+    const int img = gp < a.npix ? (int)(gp / (a.hout * a.wout)) : -1;
+    amx = fmaxf(amx, __shfl_xor(amx, 32));  // the two halves of a pixel's channels
+#pragma unroll
+    for (int o = 1; o < 32; o <<= 1) {
+      const float om = __shfl_down(amx, o);
+      const int oi = __shfl_down(img, o);
+      if ((lane & 31) + o < 32 && oi == img) amx = fmaxf(amx, om);
+    }
+    const int pi = __shfl_up(img, 1);
+    if (lane < 32 && img >= 0 && ((lane & 31) == 0 || pi != img) && amx > 0.0f) atomicMax(a.out_amax + img, __float_as_uint(amx));
   }
 }
 
@@ -959,6 +976,12 @@ __global__ void __launch_bounds__(64 * NW) cs_conv3x3_halo_resident_kernel(const
 #pragma unroll
     for (int q = 0; q < 4; ++q)
       *(conv_lds_f32x4*)(tw + l31 * RS + (8 * q + 4 * h) * 4) = f32x4{acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
+    // out_amax (images of at least 32 pixels: the wave's 32 rows lie in at most two images): the rows in front of the
+    // image boundary `bnd` belong to image img_a, the others to the next one
+    const unsigned first = (unsigned)(p0 + wave * 32);
+    const int img_a = (int)(first / (unsigned)(H * W));
+    const int bnd = (img_a + 1) * (H * W) - (int)first;
+    float m_a = 0.0f, m_b = 0.0f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int row = i * 8 + lr;
@@ -969,6 +992,20 @@ __global__ void __launch_bounds__(64 * NW) cs_conv3x3_halo_resident_kernel(const
         for (int r = 0; r < 4; ++r) o[r] = fmaxf(o[r], 0.0f);
       }
       if (g2 < a.npix) *(f32x4*)(a.out + g2 * a.cout + lc) = o;
+      if (a.out_amax && g2 < a.npix) {
+        const float m = fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3])));
+        if (row < bnd) m_a = fmaxf(m_a, m);
+        else m_b = fmaxf(m_b, m);
+      }
+    }
+    if (a.out_amax) {
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        m_a = fmaxf(m_a, __shfl_xor(m_a, o));
+        m_b = fmaxf(m_b, __shfl_xor(m_b, o));
+      }
+      if (lane == 0 && m_a > 0.0f) atomicMax(a.out_amax + img_a, __float_as_uint(m_a));
+      if (lane == 1 && m_b > 0.0f) atomicMax(a.out_amax + img_a + 1, __float_as_uint(m_b));
     }
     if (next < nitems) {
       // barriers without a wait for the stores above (only LDS traffic has to be settled)
@@ -1692,6 +1729,8 @@ __global__ void __launch_bounds__(256) cs_image_amax_kernel(const float* x, int6
 
 inline unsigned blocks_for(int64_t n) { return (unsigned)((n + 255) / 256); }
 bool g_conv_tail_split = getenv("CSVAE_NO_TAIL_SPLIT") == nullptr;  // measurements without the second launch
+// measurements with every per-image maximum taken by the reduction pass instead of the producing layers' epilogues
+bool g_conv_fused_amax = getenv("CSVAE_NO_FUSED_AMAX") == nullptr;
 // LDS bytes of cs_conv3x3_halo_split_kernel<CT, PT, NW>: three weight slots, the window, a row of zeros
 // (or, if larger, the epilogue's per-wave transposition regions)
 // terms = 2 (fp16 split): smaller tiles and rows, the rows' scales behind the window; hw > 0: plus the block's table of
@@ -1914,8 +1953,10 @@ int layer_half_kind(const CsProgram& p, const CsLayer& L) {
 
 // in_amax / out_amax: per-image maxima of the source / for the output (fp16 split, see CsConvArgs), or null
 int launch_conv(const CsProgram& p, const CsLayer& L, const float* in, const float* res, float* out, int64_t rows,
-                hipStream_t stream, const unsigned* in_amax = nullptr, unsigned* out_amax = nullptr) {
+                hipStream_t stream, const unsigned* in_amax = nullptr, unsigned* out_amax = nullptr,
+                bool* wrote_amax = nullptr) {
   const cs_layer_desc& d = L.d;
+  if (wrote_amax) *wrote_amax = false;  // set where the kernel chosen below fills out_amax
   CS_REQUIRE(rows * d.hout * d.wout < ((int64_t)1 << 31), "too many output pixels in one launch");
   CsConvArgs a;
   a.in = in; a.res = res; a.out = out;
@@ -1999,7 +2040,15 @@ int launch_conv(const CsProgram& p, const CsLayer& L, const float* in, const flo
       a.w3h = p.d_blob3h + L.wp3h_off;
       a.wexp[0] = L.wexp;
       a.in_amax = in_amax;
-      if (half) a.out_amax = out_amax;
+    }
+    // kernels whose epilogue leaves the output's per-image maxima: the fp16-split halo kernel, the generic split
+    // kernel (NHWC outputs of 32-multiple channel counts), the weight-resident kernel (images of 32 pixels and up)
+    const bool halo3 = same3 && d.cin % 32 == 0 && d.win + 1 <= 64;
+    const bool resident = halo3 && d.cin == 32 && d.cout == 32 && !d.out_nchw;
+    if (split && out_amax && d.cout % 32 == 0 && !d.out_nchw &&
+        (half || (g_conv_fused_amax && (resident ? d.hout * d.wout >= 32 : !halo3)))) {
+      a.out_amax = out_amax;
+      if (wrote_amax) *wrote_amax = true;
     }
     return launch_conv_mfma(a, stream);
   }
@@ -2037,6 +2086,7 @@ int launch_conv(const CsProgram& p, const CsLayer& L, const float* in, const flo
         for (int ph = 0; ph < 4; ++ph) a.wexp[ph] = L.wphexp[ph];
         a.in_amax = in_amax;
         a.out_amax = out_amax;
+        if (wrote_amax) *wrote_amax = out_amax != nullptr;
       }
       return launch_conv_mfma(a, stream);
     }
@@ -2378,7 +2428,12 @@ int cs_prog_launch(const CsMlpArgs& a, hipStream_t stream) {
     const size_t nlay = p->layers.size();
     std::vector<char> have(nlay + 1, 0);
     bool any_half = false;
-    for (const CsLayer& L : p->layers) any_half = any_half || layer_half_kind(*p, L) != 0;
+    std::vector<char> wants(nlay, 0);  // a later fp16-split layer reads this layer's output
+    for (const CsLayer& L : p->layers)
+      if (layer_half_kind(*p, L) != 0) {
+        any_half = true;
+        if (L.src_layer >= 0) wants[(size_t)L.src_layer] = 1;
+      }
     if (any_half) CS_HIP(hipMemsetAsync(p->amax_ws, 0, (nlay + 1) * (size_t)p->ws_rows * sizeof(unsigned), stream));
     for (size_t li = 0; li < nlay; ++li) {
       const CsLayer& L = p->layers[li];
@@ -2401,12 +2456,11 @@ int cs_prog_launch(const CsMlpArgs& a, hipStream_t stream) {
             have[slot] = 1;
           }
           in_amax = tab;
-          if (kind == 1) {
-            out_amax = p->amax_ws + li * (size_t)p->ws_rows;
-            have[li] = 1;
-          }
         }
-        if (int rc = launch_conv(*p, L, src, res, dst, rows, stream, in_amax, out_amax)) return rc;
+        if (any_half && wants[li]) out_amax = p->amax_ws + li * (size_t)p->ws_rows;
+        bool wrote = false;
+        if (int rc = launch_conv(*p, L, src, res, dst, rows, stream, in_amax, out_amax, &wrote)) return rc;
+        if (wrote) have[li] = 1;
       } else if (d.op == CS_OP_LAYERNORM) {
         hipLaunchKernelGGL(cs_layernorm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, src, dst, rows,
                            d.cin, p->d_blob + d.w_off, p->d_blob + d.b_off, d.relu);

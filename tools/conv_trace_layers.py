@@ -11,6 +11,8 @@ import sys
 
 def main():
     rows = list(csv.DictReader(open(sys.argv[1])))
+    # the library's kernels only (the framework's own copies at start-up and tear-down are not periodic)
+    rows = [r for r in rows if "cs_" in r["Kernel_Name"] or "fillBuffer" in r["Kernel_Name"]]
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     names = [r["Kernel_Name"] for r in rows]
     dur = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows]

@@ -82,14 +82,10 @@ def program_layer_costs(layers):
 def layer_runs_fp16_split(L):
     """Whether a layer of a layer program runs the fp16-split (2-term) arithmetic when it is selected
     (layer_half_kind in csrc/cs_net.hip): the convolutions of the matrix kernels (16 input channels and up, NHWC
-    input) except the 32 -> 32 channel same-size 3x3 layers of the weight-resident kernel and the convolutions to at
-    most 4 channels; linear layers and those keep the 3-term bf16 split."""
+    input) except the convolutions to at most 4 channels; linear layers and those keep the 3-term bf16 split."""
     if L.op != CS_OP_CONV or L.in_nchw or L.cin < 16:
         return False
-    if L.cout <= 4 and L.cin in (32, 64, 128, 256) and L.upsample == 1 and L.ksize in (1, 3):
-        return False
-    same3 = L.ksize == 3 and L.stride == 1 and L.pad == 1 and L.upsample == 1 and L.hin == L.hout and L.win == L.wout
-    return not (same3 and L.cin == 32 and L.cout == 32 and not L.out_nchw)
+    return not (L.cout <= 4 and L.cin in (32, 64, 128, 256) and L.upsample == 1 and L.ksize in (1, 3))
 
 
 def layerwise_ideal_seconds(layers, rows, flops_per_s, bytes_per_s=8.0e12, fp16_split_flops_per_s=None):

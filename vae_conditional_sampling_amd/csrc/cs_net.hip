@@ -825,10 +825,13 @@ __global__ void __launch_bounds__(64 * NW) cs_conv3x3_halo_split_kernel(const Cs
 // workgroup per CU walks over items of 32*NW pixels: the next item's window is requested before the current item's
 // matrix instructions and staged behind them, the residual rows are requested before them too, the stores are never
 // waited for; two barriers per item, none inside it.
-template <int NW>
+// TERMS = 2: the fp16 split of cs_conv3x3_halo_split_kernel (two fp16 terms, three products, 128-byte window rows with
+// its slot swizzle, weights from a.w3h, operands of image n scaled by the power of two from in_amax[n], fetched with
+// the window rows).
+template <int NW, int TERMS = 3>
 __global__ void __launch_bounds__(64 * NW) cs_conv3x3_halo_resident_kernel(const CsConvArgs a, int NR, int NP, int nitems) {
   constexpr int NTHR = 64 * NW, RPP = NTHR / 8;
-  constexpr int ROWB = 192, W_B = 6144, NPMAX = 6;
+  constexpr int ROWB = 64 * TERMS, W_B = 2048 * TERMS, NPMAX = 6;
   constexpr int RS = 128 + 16;  // transposition row: 32 channels + padding
   extern __shared__ __attribute__((aligned(1024))) unsigned char s_raw[];
   lds_byte* s_w = (lds_byte*)s_raw;                     // [9][W_B]
@@ -842,6 +845,7 @@ __global__ void __launch_bounds__(64 * NW) cs_conv3x3_halo_resident_kernel(const
   if (NW == 8 && wave >= 4) __builtin_amdgcn_s_setprio(1);
 
   f32x4 rh[NPMAX];
+  unsigned rg[NPMAX];  // TERMS = 2: bits of the row's image maximum
   auto fetch_halo = [&](int item) {
     const int64_t q0 = (int64_t)item * (32 * NW) - (W + 1);
 #pragma unroll
@@ -849,15 +853,32 @@ __global__ void __launch_bounds__(64 * NW) cs_conv3x3_halo_resident_kernel(const
       const int row = (tid >> 3) + RPP * p;
       const int64_t q = q0 + row;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (p < NP && row < NR && q >= 0 && q < a.npix) v = *(const f32x4*)(a.in + q * 32 + c4 * 4);
+      unsigned gb = 0u;
+      if (p < NP && row < NR && q >= 0 && q < a.npix) {
+        v = *(const f32x4*)(a.in + q * 32 + c4 * 4);
+        if (TERMS == 2) gb = a.in_amax[(unsigned)q / (unsigned)(H * W)];
+      }
       rh[p] = v;
+      rg[p] = gb;
     }
   };
   auto stash_halo = [&]() {
 #pragma unroll
     for (int p = 0; p < NPMAX; ++p) {
       const int row = (tid >> 3) + RPP * p;
-      if (p < NP && row < NR) {
+      if (TERMS == 2) {
+        if (p < NP && row < NR) {
+          const f32x4 v = rh[p];
+          const float g = conv_image_scale(rg[p]);
+          const unsigned a0 = conv_mix_pk_f16(v.x, v.y, g), b0 = conv_mix_pk_f16(v.z, v.w, g);
+          const float r0 = conv_mix_rem_lo(v.x, g, a0), r1 = conv_mix_rem_hi(v.y, g, a0);
+          const float r2 = conv_mix_rem_lo(v.z, g, b0), r3 = conv_mix_rem_hi(v.w, g, b0);
+          const unsigned a1 = conv_cvt_pk_f16(r0, r1), b1 = conv_cvt_pk_f16(r2, r3);
+          const unsigned o = (unsigned)row * ROWB + ((unsigned)((c4 >> 1) ^ ((row >> 1) & 7)) << 4) + ((unsigned)(c4 & 1) << 3);
+          *(__attribute__((address_space(3))) u32x2n*)(s_halo + o) = u32x2n{a0, b0};
+          *(__attribute__((address_space(3))) u32x2n*)(s_halo + (o ^ 64u)) = u32x2n{a1, b1};
+        }
+      } else if (p < NP && row < NR) {
         const f32x4 v = rh[p];
         const unsigned a0 = conv_cvt_pk(v.x, v.y), b0 = conv_cvt_pk(v.z, v.w);
         const float r0 = v.x - __uint_as_float(a0 << 16), r1 = v.y - __uint_as_float(a0 & 0xffff0000u);
@@ -873,11 +894,12 @@ __global__ void __launch_bounds__(64 * NW) cs_conv3x3_halo_resident_kernel(const
     }
   };
 
-  // all weight tiles: tile of tap t = [t][cin/32 = 1][cout_p/32 = 1] brick; 54 copies of 1 KiB over the waves
+  // all weight tiles: tile of tap t = [t][cin/32 = 1][cout_p/32 = 1] brick; 9 * W_B / 1024 copies of 1 KiB over the waves
   {
     const unsigned ring_lds = cs_scalar_u32((unsigned)(size_t)s_w);
-    for (int piece = wave; piece < 54; piece += NW) {
-      const unsigned long long src = (unsigned long long)((const unsigned char*)a.w3 + (int64_t)piece * 1024);
+    for (int piece = wave; piece < 9 * W_B / 1024; piece += NW) {
+      const unsigned long long src =
+          (unsigned long long)((TERMS == 2 ? (const unsigned char*)a.w3h : (const unsigned char*)a.w3) + (int64_t)piece * 1024);
       const void* ssrc =
           (const void*)(((unsigned long long)cs_scalar_u32((unsigned)(src >> 32)) << 32) | cs_scalar_u32((unsigned)src));
       cs_dma16(ssrc, (unsigned)lane * 16u, ring_lds + (unsigned)piece * 1024u);
@@ -914,11 +936,14 @@ __global__ void __launch_bounds__(64 * NW) cs_conv3x3_halo_resident_kernel(const
     }
     auto b_addr = [&](int tap) -> unsigned {
       const int rowB = row0 + (tap / 3) * W + (tap % 3);
-      const unsigned o = (unsigned)rowB * ROWB + (unsigned)((h ^ ((rowB >> 2) & 3)) << 4);
+      const unsigned o = (unsigned)rowB * ROWB + (unsigned)((h ^ (TERMS == 2 ? (rowB >> 1) & 7 : (rowB >> 2) & 3)) << 4);
       return ((tapmask >> tap) & 1u) ? o : zero_off + (unsigned)(h << 4);
     };
     // requests that the matrix instructions below cover: the next item's window, this item's residual rows
     const int next = item + gridDim.x;
+    // TERMS = 2: the maximum of the lane's pixel's image, for the way back to true values
+    unsigned my_amax = 0u;
+    if (TERMS == 2 && gp < a.npix) my_amax = a.in_amax[(unsigned)gp / (unsigned)(H * W)];
     if (next < nitems) fetch_halo(next);
     f32x4 rs[4];
 #pragma unroll
@@ -931,12 +956,13 @@ __global__ void __launch_bounds__(64 * NW) cs_conv3x3_halo_resident_kernel(const
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-    u32x4n wr[2][3], br[2][3];
+    u32x4n wr[2][TERMS], br[2][TERMS];
     unsigned bo = b_addr(0), bn = 0;
+    auto b_term = [&](unsigned o, int tm) -> unsigned { return TERMS == 2 ? o ^ ((unsigned)tm << 6) : o + (unsigned)tm * 64u; };
 #pragma unroll
-    for (int tm = 0; tm < 3; ++tm) {
+    for (int tm = 0; tm < TERMS; ++tm) {
       wr[0][tm] = *(const lds_u32x4n*)(wl + tm * 1024);
-      br[0][tm] = *(const lds_u32x4n*)(s_halo + bo + tm * 64);
+      br[0][tm] = *(const lds_u32x4n*)(s_halo + b_term(bo, tm));
     }
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
@@ -946,32 +972,45 @@ __global__ void __launch_bounds__(64 * NW) cs_conv3x3_halo_resident_kernel(const
         // fragments of the next group (the first group of the next tap behind the second one)
         if (s == 0) {
 #pragma unroll
-          for (int tm = 0; tm < 3; ++tm) {
-            wr[1][tm] = *(const lds_u32x4n*)(wl + tap * W_B + (3 + tm) * 1024);
-            br[1][tm] = *(const lds_u32x4n*)(s_halo + (bo ^ 32u) + tm * 64);
+          for (int tm = 0; tm < TERMS; ++tm) {
+            wr[1][tm] = *(const lds_u32x4n*)(wl + tap * W_B + (TERMS + tm) * 1024);
+            br[1][tm] = *(const lds_u32x4n*)(s_halo + b_term(bo ^ 32u, tm));
           }
         } else if (tap < 8) {
 #pragma unroll
-          for (int tm = 0; tm < 3; ++tm) {
+          for (int tm = 0; tm < TERMS; ++tm) {
             wr[0][tm] = *(const lds_u32x4n*)(wl + (tap + 1) * W_B + tm * 1024);
-            br[0][tm] = *(const lds_u32x4n*)(s_halo + bn + tm * 64);
+            br[0][tm] = *(const lds_u32x4n*)(s_halo + b_term(bn, tm));
           }
         }
-        const u32x4n(&w)[3] = wr[s];
-        const u32x4n(&b)[3] = br[s];
-        CS_CONV_MFMA32(w[0], b[0], acc);
-        CS_CONV_MFMA32(w[0], b[1], acc);
-        __builtin_amdgcn_sched_barrier(0);
-        CS_CONV_MFMA32(w[1], b[0], acc);
-        CS_CONV_MFMA32(w[0], b[2], acc);
-        __builtin_amdgcn_sched_barrier(0);
-        CS_CONV_MFMA32(w[1], b[1], acc);
-        CS_CONV_MFMA32(w[2], b[0], acc);
-        __builtin_amdgcn_sched_barrier(0);
+        const u32x4n(&w)[TERMS] = wr[s];
+        const u32x4n(&b)[TERMS] = br[s];
+        if constexpr (TERMS == 2) {
+          CS_CONV_MFMA32H(w[0], b[0], acc);
+          CS_CONV_MFMA32H(w[0], b[1], acc);
+          __builtin_amdgcn_sched_barrier(0);
+          CS_CONV_MFMA32H(w[1], b[0], acc);
+          __builtin_amdgcn_sched_barrier(0);
+        } else {
+          CS_CONV_MFMA32(w[0], b[0], acc);
+          CS_CONV_MFMA32(w[0], b[1], acc);
+          __builtin_amdgcn_sched_barrier(0);
+          CS_CONV_MFMA32(w[1], b[0], acc);
+          CS_CONV_MFMA32(w[0], b[TERMS - 1], acc);
+          __builtin_amdgcn_sched_barrier(0);
+          CS_CONV_MFMA32(w[1], b[1], acc);
+          CS_CONV_MFMA32(w[TERMS - 1], b[0], acc);
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
       bo = bn;
     }
     cs_mfma_drain();
+    if constexpr (TERMS == 2) {  // back to true values, in one exact step
+      const int e = 127 - (int)(__float_as_uint(conv_image_scale(my_amax)) >> 23) - a.wexp[0];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = __builtin_ldexpf(acc[r], e);
+    }
     // epilogue: transpose through the wave's LDS region so that a store covers 8 whole pixel rows
 #pragma unroll
     for (int q = 0; q < 4; ++q)
@@ -1380,6 +1419,7 @@ __global__ void __launch_bounds__(256) cs_conv3x3_fewin_kernel(const CsConvArgs 
   __syncthreads();
   const int ppp = 256 / tpp;  // pixels per pass
   const float inv_w = 1.0f / (float)W;
+  float amx = 0.0f;  // out_amax: the largest magnitude this thread stores (the block is one image)
   for (int px = threadIdx.x / tpp; px < hw; px += ppp) {
     const int oh = (int)(((float)px + 0.5f) * inv_w), ow = px - oh * W;  // exact: (px + 0.5) / W is never within 1/(2W) of an integer
     const float* ip = s_img + oh * WP + ow;  // top-left corner of the pixel's 3x3 window in the bordered image
@@ -1400,6 +1440,12 @@ __global__ void __launch_bounds__(256) cs_conv3x3_fewin_kernel(const CsConvArgs 
       for (int v = 0; v < 4; ++v) o[v] = fmaxf(o[v], 0.0f);
     }
     *(f32x4*)(a.out + gp * a.cout + co) = o;
+    amx = fmaxf(fmaxf(amx, fmaxf(fabsf(o[0]), fabsf(o[1]))), fmaxf(fabsf(o[2]), fabsf(o[3])));
+  }
+  if (a.out_amax) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) amx = fmaxf(amx, __shfl_xor(amx, o));
+    if ((threadIdx.x & 63) == 0 && amx > 0.0f) atomicMax(a.out_amax + n, __float_as_uint(amx));
   }
 }
 
@@ -1539,21 +1585,39 @@ __global__ void __launch_bounds__(256) cs_avgpool_kernel(const float* in, float*
 
 // F.interpolate(mode='nearest', size=...) over NHWC: src = min(floor(dst * (in/out)), in-1) with
 // the scale in float32, as torch computes it.
+// out_amax (or null): per-image maxima of the output (atomic max of the bits of |value|, zeroed by the caller): one
+// atomic per wavefront whose elements lie in one image, one per lane otherwise.
 __global__ void __launch_bounds__(256) cs_resize_kernel(const float* in, float* out, int64_t n, int hin, int win,
-                                                        int hout, int wout, int c) {
+                                                        int hout, int wout, int c, unsigned* out_amax) {
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= n * hout * wout * c) return;
-  const int ch = (int)(idx % c);
-  int64_t t = idx / c;
-  const int ow = (int)(t % wout);
-  t /= wout;
-  const int oh = (int)(t % hout);
-  const int64_t r = t / hout;
-  const float sh = (float)hin / (float)hout, sw = (float)win / (float)wout;
-  int ih = (int)floorf((float)oh * sh), iw = (int)floorf((float)ow * sw);
-  ih = ih < hin - 1 ? ih : hin - 1;
-  iw = iw < win - 1 ? iw : win - 1;
-  out[idx] = in[((r * hin + ih) * win + iw) * c + ch];
+  const bool valid = idx < n * hout * wout * c;
+  float v = 0.0f;
+  int64_t r = -1;
+  if (valid) {
+    const int ch = (int)(idx % c);
+    int64_t t = idx / c;
+    const int ow = (int)(t % wout);
+    t /= wout;
+    const int oh = (int)(t % hout);
+    r = t / hout;
+    const float sh = (float)hin / (float)hout, sw = (float)win / (float)wout;
+    int ih = (int)floorf((float)oh * sh), iw = (int)floorf((float)ow * sw);
+    ih = ih < hin - 1 ? ih : hin - 1;
+    iw = iw < win - 1 ? iw : win - 1;
+    v = in[((r * hin + ih) * win + iw) * c + ch];
+    out[idx] = v;
+  }
+  if (out_amax) {
+    const int64_t r0 = __shfl(r, 0), r63 = __shfl(r, 63);
+    float m = fabsf(v);
+    if (r0 == r63 && r0 >= 0) {
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+      if ((threadIdx.x & 63) == 0 && m > 0.0f) atomicMax(out_amax + r0, __float_as_uint(m));
+    } else if (valid && m > 0.0f) {
+      atomicMax(out_amax + r, __float_as_uint(m));
+    }
+  }
 }
 
 // ----------------------------------------------------------------------------------------
@@ -1807,21 +1871,29 @@ int launch_conv_mfma(const CsConvArgs& a, hipStream_t stream) {
     if (same3 && a.cin == 32 && a.cout == 32 && !a.out_nchw && a.npix < ((int64_t)1 << 31)) {
       // weights resident in LDS, persistent workgroups (cs_conv3x3_halo_resident_kernel)
       constexpr int NW_ = 8;
+      const bool half = a.w3h != nullptr && a.in_amax != nullptr;  // fp16 split
+      const int terms = half ? 2 : 3;
       const int NR = 32 * NW_ + 2 * (a.win + 1), NP = (NR * 8 + 64 * NW_ - 1) / (64 * NW_);
-      const size_t lds = (size_t)9 * 6144 + (((size_t)NR * 192 + 256 + 1023) & ~(size_t)1023) + (size_t)NW_ * 32 * 144;
+      const size_t lds = (size_t)9 * 2048 * terms + (((size_t)NR * 64 * terms + 256 + 1023) & ~(size_t)1023) + (size_t)NW_ * 32 * 144;
       CS_REQUIRE(NP <= 6 && lds <= 160 * 1024, "halo window does not fit");
       static bool attr_set[64] = {};
       static int ncu[64] = {};
       if (!attr_set[dev]) {
-        CS_HIP(hipFuncSetAttribute((const void*)cs_conv3x3_halo_resident_kernel<NW_>,
+        CS_HIP(hipFuncSetAttribute((const void*)cs_conv3x3_halo_resident_kernel<NW_, 3>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        CS_HIP(hipFuncSetAttribute((const void*)cs_conv3x3_halo_resident_kernel<NW_, 2>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         CS_HIP(hipDeviceGetAttribute(&ncu[dev], hipDeviceAttributeMultiprocessorCount, dev));
         attr_set[dev] = true;
       }
       const int nitems = (int)((a.npix + 32 * NW_ - 1) / (32 * NW_));
       const int grid = nitems < ncu[dev] ? nitems : ncu[dev];
-      hipLaunchKernelGGL((cs_conv3x3_halo_resident_kernel<NW_>), dim3((unsigned)grid), dim3(64 * NW_), lds, stream, a, NR,
-                         NP, nitems);
+      if (half)
+        hipLaunchKernelGGL((cs_conv3x3_halo_resident_kernel<NW_, 2>), dim3((unsigned)grid), dim3(64 * NW_), lds, stream, a, NR,
+                           NP, nitems);
+      else
+        hipLaunchKernelGGL((cs_conv3x3_halo_resident_kernel<NW_, 3>), dim3((unsigned)grid), dim3(64 * NW_), lds, stream, a, NR,
+                           NP, nitems);
     } else if (same3 || phases4) {
       // fp16 split where the caller supplied its weights and the input's per-image maxima
       const bool half = a.w3h != nullptr && a.in_amax != nullptr;
@@ -1926,9 +1998,9 @@ bool fewout_eligible(const cs_layer_desc& d) {
 }
 
 // How launch_conv runs layer L under the fp16-split arithmetic: 0 = not at all (another arithmetic is selected, a
-// weight is not finite, or the layer runs on a kernel without that arithmetic: the weight-resident 32 -> 32 channel
-// kernel, the few-channel and direct kernels, linear layers), 1 = on the halo kernel (same-size and four-phase
-// upsampled 3x3 convolutions; its epilogue leaves the per-image maxima of the output), 2 = on the generic kernel.
+// weight is not finite, or the layer runs on a kernel without that arithmetic: the few-channel and direct kernels,
+// linear layers), 1 = on the halo kernel (same-size and four-phase upsampled 3x3 convolutions; its epilogue leaves
+// the per-image maxima of the output), 2 = on the generic kernel, 3 = on the weight-resident 32 -> 32 channel kernel.
 int layer_half_kind(const CsProgram& p, const CsLayer& L) {
   const cs_layer_desc& d = L.d;
   if ((p.arith >= 0 ? p.arith : cs_mlp_arith()) != CS_ARITH_F16X2 || L.wp3_off < 0 || L.wp3h_off < 0) return 0;
@@ -1936,7 +2008,7 @@ int layer_half_kind(const CsProgram& p, const CsLayer& L) {
   const bool halo_ok = d.cin % 32 == 0 && d.cout % 32 == 0 && !d.out_nchw && d.win + 1 <= 64;
   if (L.up_mode == CS_UP_NONE) {
     const bool same3 = d.ksize == 3 && d.stride == 1 && d.pad == 1 && d.upsample == 1 && d.hin == d.hout && d.win == d.wout;
-    if (same3 && d.cin == 32 && d.cout == 32 && !d.out_nchw) return 0;  // weight-resident kernel
+    if (same3 && d.cin == 32 && d.cout == 32 && !d.out_nchw) return d.win + 1 <= 64 ? 3 : 2;  // weight-resident kernel
     return same3 && halo_ok ? 1 : 2;
   }
   if (L.up_mode == CS_UP_REPLICATE) return 2;
@@ -2015,6 +2087,10 @@ int launch_conv(const CsProgram& p, const CsLayer& L, const float* in, const flo
   if (L.wp_off < 0 && same3 && d.cin <= 3 && !d.out_nchw && d.cout >= 16 && d.cout <= 256 && (d.cout & (d.cout - 1)) == 0 &&
       (size_t)d.cin * (d.hin + 2) * (d.win + 2) * 4 <= 48 * 1024) {
     a.w = p.d_blob + d.w_off;
+    if (g_conv_fused_amax && out_amax) {  // a block of this kernel is one image
+      a.out_amax = out_amax;
+      if (wrote_amax) *wrote_amax = true;
+    }
     const size_t lds = (size_t)d.cin * (d.hin + 2) * (d.win + 2) * 4;
     if (d.cin == 1) hipLaunchKernelGGL((cs_conv3x3_fewin_kernel<1>), dim3((unsigned)rows), dim3(256), lds, stream, a);
     else if (d.cin == 2) hipLaunchKernelGGL((cs_conv3x3_fewin_kernel<2>), dim3((unsigned)rows), dim3(256), lds, stream, a);
@@ -2468,8 +2544,10 @@ int cs_prog_launch(const CsMlpArgs& a, hipStream_t stream) {
         hipLaunchKernelGGL(cs_avgpool_kernel, dim3(blocks_for(rows * d.cin)), dim3(256), 0, stream, src, dst, rows,
                            d.hin * d.win, d.cin);
       } else {
+        unsigned* oam = (any_half && wants[li] && g_conv_fused_amax) ? p->amax_ws + li * (size_t)p->ws_rows : nullptr;
         hipLaunchKernelGGL(cs_resize_kernel, dim3(blocks_for(rows * d.hout * d.wout * d.cin)), dim3(256), 0, stream,
-                           src, dst, rows, d.hin, d.win, d.hout, d.wout, d.cin);
+                           src, dst, rows, d.hin, d.win, d.hout, d.wout, d.cin, oam);
+        if (oam) have[li] = 1;
       }
     }
     if (a.mode == CS_MLP_ENC)

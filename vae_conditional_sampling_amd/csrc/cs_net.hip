@@ -55,6 +55,11 @@ struct CsConvArgs {
   int amax_lds;
 };
 
+// Joins `bits` (the bits of a non-negative float) to a per-image maximum in global memory.  (Measured and not kept: a
+// load of the word in front of the atomic, to skip atomics that cannot raise it -- thousands of wavefronts reading
+// one word serialise on it as much as their atomics do.  Callers keep the number of joins per image small instead.)
+__device__ __forceinline__ void conv_amax_join(unsigned* p, unsigned bits) { atomicMax(p, bits); }
+
 __device__ __forceinline__ int64_t conv_out_pix(const CsConvArgs& a, int64_t gp, int ooh, int oow) {
   if (a.osc == 1) return gp;
   const int hw = a.hout * a.wout;
@@ -124,7 +129,7 @@ __device__ __forceinline__ void conv_store(const CsConvArgs& a, const f32x16 (&a
       if ((lane & 31) + o < 32 && oi == img) amx = fmaxf(amx, om);
     }
     const int pi = __shfl_up(img, 1);
-    if (lane < 32 && img >= 0 && ((lane & 31) == 0 || pi != img) && amx > 0.0f) atomicMax(a.out_amax + img, __float_as_uint(amx));
+    if (lane < 32 && img >= 0 && ((lane & 31) == 0 || pi != img) && amx > 0.0f) conv_amax_join(a.out_amax + img, __float_as_uint(amx));
   }
 }
 
@@ -810,7 +815,7 @@ __global__ void __launch_bounds__(64 * NW) cs_conv3x3_halo_split_kernel(const Cs
       __syncthreads();
       for (int r = tid; r < (PX * NW) / hw + 2; r += NTHR) {
         const unsigned v = s_amax[r];
-        if (v != 0u) atomicMax(a.out_amax + img0 + r, v);
+        if (v != 0u) conv_amax_join(a.out_amax + img0 + r, v);
       }
     }
   } else {
@@ -1043,8 +1048,8 @@ __global__ void __launch_bounds__(64 * NW) cs_conv3x3_halo_resident_kernel(const
         m_a = fmaxf(m_a, __shfl_xor(m_a, o));
         m_b = fmaxf(m_b, __shfl_xor(m_b, o));
       }
-      if (lane == 0 && m_a > 0.0f) atomicMax(a.out_amax + img_a, __float_as_uint(m_a));
-      if (lane == 1 && m_b > 0.0f) atomicMax(a.out_amax + img_a + 1, __float_as_uint(m_b));
+      if (lane == 0 && m_a > 0.0f) conv_amax_join(a.out_amax + img_a, __float_as_uint(m_a));
+      if (lane == 1 && m_b > 0.0f) conv_amax_join(a.out_amax + img_a + 1, __float_as_uint(m_b));
     }
     if (next < nitems) {
       // barriers without a wait for the stores above (only LDS traffic has to be settled)
@@ -1445,7 +1450,7 @@ __global__ void __launch_bounds__(256) cs_conv3x3_fewin_kernel(const CsConvArgs 
   if (a.out_amax) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) amx = fmaxf(amx, __shfl_xor(amx, o));
-    if ((threadIdx.x & 63) == 0 && amx > 0.0f) atomicMax(a.out_amax + n, __float_as_uint(amx));
+    if ((threadIdx.x & 63) == 0 && amx > 0.0f) conv_amax_join(a.out_amax + n, __float_as_uint(amx));
   }
 }
 
@@ -1585,39 +1590,23 @@ __global__ void __launch_bounds__(256) cs_avgpool_kernel(const float* in, float*
 
 // F.interpolate(mode='nearest', size=...) over NHWC: src = min(floor(dst * (in/out)), in-1) with
 // the scale in float32, as torch computes it.
-// out_amax (or null): per-image maxima of the output (atomic max of the bits of |value|, zeroed by the caller): one
-// atomic per wavefront whose elements lie in one image, one per lane otherwise.
+// (Per-image maxima of the output are left to the reduction pass: one join per wavefront from this kernel's 10^5
+// blocks took four times the kernel's own time on the words of 2048 images.)
 __global__ void __launch_bounds__(256) cs_resize_kernel(const float* in, float* out, int64_t n, int hin, int win,
-                                                        int hout, int wout, int c, unsigned* out_amax) {
+                                                        int hout, int wout, int c) {
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  const bool valid = idx < n * hout * wout * c;
-  float v = 0.0f;
-  int64_t r = -1;
-  if (valid) {
-    const int ch = (int)(idx % c);
-    int64_t t = idx / c;
-    const int ow = (int)(t % wout);
-    t /= wout;
-    const int oh = (int)(t % hout);
-    r = t / hout;
-    const float sh = (float)hin / (float)hout, sw = (float)win / (float)wout;
-    int ih = (int)floorf((float)oh * sh), iw = (int)floorf((float)ow * sw);
-    ih = ih < hin - 1 ? ih : hin - 1;
-    iw = iw < win - 1 ? iw : win - 1;
-    v = in[((r * hin + ih) * win + iw) * c + ch];
-    out[idx] = v;
-  }
-  if (out_amax) {
-    const int64_t r0 = __shfl(r, 0), r63 = __shfl(r, 63);
-    float m = fabsf(v);
-    if (r0 == r63 && r0 >= 0) {
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-      if ((threadIdx.x & 63) == 0 && m > 0.0f) atomicMax(out_amax + r0, __float_as_uint(m));
-    } else if (valid && m > 0.0f) {
-      atomicMax(out_amax + r, __float_as_uint(m));
-    }
-  }
+  if (idx >= n * hout * wout * c) return;
+  const int ch = (int)(idx % c);
+  int64_t t = idx / c;
+  const int ow = (int)(t % wout);
+  t /= wout;
+  const int oh = (int)(t % hout);
+  const int64_t r = t / hout;
+  const float sh = (float)hin / (float)hout, sw = (float)win / (float)wout;
+  int ih = (int)floorf((float)oh * sh), iw = (int)floorf((float)ow * sw);
+  ih = ih < hin - 1 ? ih : hin - 1;
+  iw = iw < win - 1 ? iw : win - 1;
+  out[idx] = in[((r * hin + ih) * win + iw) * c + ch];
 }
 
 // ----------------------------------------------------------------------------------------
@@ -1787,7 +1776,7 @@ __global__ void __launch_bounds__(256) cs_image_amax_kernel(const float* x, int6
       for (int64_t i = 4 * n4 + threadIdx.x; i < elems; i += 256) m = fmaxf(m, fabsf(xi[i]));
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-    if ((threadIdx.x & 63) == 0 && m > 0.0f) atomicMax(out + img, __float_as_uint(m));
+    if ((threadIdx.x & 63) == 0 && m > 0.0f) conv_amax_join(out + img, __float_as_uint(m));
   }
 }
 
@@ -2544,10 +2533,8 @@ int cs_prog_launch(const CsMlpArgs& a, hipStream_t stream) {
         hipLaunchKernelGGL(cs_avgpool_kernel, dim3(blocks_for(rows * d.cin)), dim3(256), 0, stream, src, dst, rows,
                            d.hin * d.win, d.cin);
       } else {
-        unsigned* oam = (any_half && wants[li] && g_conv_fused_amax) ? p->amax_ws + li * (size_t)p->ws_rows : nullptr;
         hipLaunchKernelGGL(cs_resize_kernel, dim3(blocks_for(rows * d.hout * d.wout * d.cin)), dim3(256), 0, stream,
-                           src, dst, rows, d.hin, d.win, d.hout, d.wout, d.cin, oam);
-        if (oam) have[li] = 1;
+                           src, dst, rows, d.hin, d.win, d.hout, d.wout, d.cin);
       }
     }
     if (a.mode == CS_MLP_ENC)

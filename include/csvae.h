@@ -432,8 +432,12 @@ int cs_rng_uniform64(const cs_rng* rng, uint32_t stream_id, int64_t rows, int32_
  *                    exact-float32 kernel or lower, for inputs and weights of any scale, outliers and in-row spreads
  *                    of 1e4 included (tests/test_gpu_f16x2_arith.py); they are not bit-identical to it.  A network
  *                    with a non-finite weight has no fp16 stream: under the process-wide setting it runs in
- *                    CS_ARITH_BF16X3, a handle told CS_ARITH_F16X2 itself (cs_mlp_set_arith) is refused.  Fused MLP
- *                    kernel only; layer-program networks keep CS_ARITH_BF16X3 under this setting.
+ *                    CS_ARITH_BF16X3, a handle told CS_ARITH_F16X2 itself (cs_mlp_set_arith) is refused.  In
+ *                    layer-program networks (cs_net_create) the matrix convolutions run this arithmetic with ONE power
+ *                    of two per image (all taps of an output pixel share a scale; an image's result does not depend on
+ *                    the other images of a launch), taken from the largest magnitude of the image's activation, which
+ *                    the producing layer leaves in the handle's workspace (tests/test_gpu_conv_f16x2.py); their linear
+ *                    layers and convolutions to at most 4 channels keep CS_ARITH_BF16X3.
  *   CS_ARITH_BF16X3  every float32 operand split exactly into three bfloat16 terms (8 + 8 + 8 significand bits), a
  *                    product accumulated in float32 from the six leading term products; the neglected terms are below
  *                    2^-23 of |a||b|.  Float32-equivalent like the default (tests/test_gpu_split_arith.py) with
@@ -448,8 +452,8 @@ int cs_rng_uniform64(const cs_rng* rng, uint32_t stream_id, int64_t rows, int32_
  *                    kernel only; layer-program networks keep CS_ARITH_BF16X3 under this setting.
  * The setting is process-wide and applies to launches made after the call; the environment variable
  * CSVAE_MLP_ARITH (f16x2 | bf16x3 | f32 | bf16) gives the initial value.  It also selects the kernels of the matrix-core
- * convolution / linear layers of layer-program networks (cs_net_create): exact float32 under CS_ARITH_F32, the
- * bfloat16 split otherwise. */
+ * convolution / linear layers of layer-program networks (cs_net_create): exact float32 under CS_ARITH_F32, the fp16
+ * split of the convolutions under CS_ARITH_F16X2, the bfloat16 split otherwise. */
 enum { CS_ARITH_DEFAULT = -1, CS_ARITH_F32 = 0, CS_ARITH_BF16X3 = 1, CS_ARITH_BF16 = 2, CS_ARITH_F16X2 = 3 };
 int cs_set_mlp_arith(int arith);
 int cs_get_mlp_arith(void);

@@ -513,7 +513,7 @@ __device__ __forceinline__ float conv_image_scale(unsigned bits) {
   return __uint_as_float((unsigned)(127 - (be - 127 - 14)) << 23);
 }
 template <int CT, int PT, int NW, bool PHASE, int TERMS = 3>
-__global__ void __launch_bounds__(64 * NW) cs_conv3x3_halo_split_kernel(const CsConvArgs a, int NR, int NP) {
+__global__ void __launch_bounds__(64 * NW, 2) cs_conv3x3_halo_split_kernel(const CsConvArgs a, int NR, int NP) {
   // PHASE: phase (pa, pb) = (blockIdx.z >> 1, blockIdx.z & 1) of a nearest-neighbour-upsampled 3x3 convolution, a 2x2
   // convolution of the input at its own resolution (see CsUpsampleMode): tap (dh, dw) reads the input pixel that tap
   // (pa + dh, pb + dw) of a same-size 3x3 convolution reads, so the window, the tap masks and the fragment addresses
@@ -1784,13 +1784,19 @@ inline unsigned blocks_for(int64_t n) { return (unsigned)((n + 255) / 256); }
 bool g_conv_tail_split = getenv("CSVAE_NO_TAIL_SPLIT") == nullptr;  // measurements without the second launch
 // measurements with every per-image maximum taken by the reduction pass instead of the producing layers' epilogues
 bool g_conv_fused_amax = getenv("CSVAE_NO_FUSED_AMAX") == nullptr;
+// fp16 split, same-size 64-channel layers: 256-pixel blocks of 4 waves, two to a CU (74 KB of LDS each), so that one
+// block's prologue and epilogue run under the other's matrix instructions (Omniglot encoder 6.05 -> 5.89 ms, decoder
+// 7.51 -> 7.24 on one box; the same shape measured slower for the upsampling form, and 128-pixel 4-wave blocks at two per
+// CU for the 128+-channel layers 4 % slower: twice the weight stream per CU).  CSVAE_HALO_224=0: 512-pixel 8-wave blocks.
+bool g_halo_224 = getenv("CSVAE_HALO_224") == nullptr || atoi(getenv("CSVAE_HALO_224")) != 0;
 // LDS bytes of cs_conv3x3_halo_split_kernel<CT, PT, NW>: three weight slots, the window, a row of zeros
 // (or, if larger, the epilogue's per-wave transposition regions)
 // terms = 2 (fp16 split): smaller tiles and rows, the rows' scales behind the window; hw > 0: plus the block's table of
 // per-image output maxima at the end (its offset: halo3_lds with hw = 0)
 inline size_t halo3_lds(int ct, int pt, int nw, int win, int terms = 3, int hw = 0) {
+  const int nslot = terms == 2 ? 4 : 3;
   const size_t nr = (size_t)(32 * pt * nw + 2 * (win + 1));
-  const size_t loop = (size_t)(terms == 2 ? 4 : 3) * ct * 2048 * terms + nr * 64 * terms + 256 + (terms == 2 ? nr * 4 : 0);
+  const size_t loop = (size_t)nslot * ct * 2048 * terms + nr * 64 * terms + 256 + (terms == 2 ? nr * 4 : 0);
   const size_t store = (size_t)nw * 32 * pt * (ct * 128 + 16);
   const size_t main = ((loop > store ? loop : store) + 15) & ~(size_t)15;
   return main + (hw > 0 ? 4 * ((size_t)(32 * pt * nw) / hw + 2) : 0);
@@ -1892,6 +1898,7 @@ int launch_conv_mfma(const CsConvArgs& a, hipStream_t stream) {
       auto halo = [&](const CsConvArgs& a, bool tail) -> int {  // `a` of the macros: this launch's part of the images
         if (tail) CS_HALO3_LAUNCH(1, 1, 4);
         else if (big == 0) CS_HALO3_LAUNCH(4, 1, 8);
+        else if (big == 1 && half && g_halo_224 && !phases4) CS_HALO3_LAUNCH_(2, 2, 4, false, 2);
         else if (big == 1) CS_HALO3_LAUNCH(2, 2, 8);
         else if (big == 2) CS_HALO3_LAUNCH(2, 1, 8);
         else CS_HALO3_LAUNCH(1, 2, 4);
@@ -1904,7 +1911,7 @@ int launch_conv_mfma(const CsConvArgs& a, hipStream_t stream) {
       // spread over all CUs and whose matrix-instruction chains are an eighth as long.
       static int ncu[64] = {};
       if (!ncu[dev]) CS_HIP(hipDeviceGetAttribute(&ncu[dev], hipDeviceAttributeMultiprocessorCount, dev));
-      const int pxb = big == 1 ? 512 : 256, cob = big == 0 ? 128 : big == 3 ? 32 : 64;
+      const int pxb = big == 1 && !(half && g_halo_224 && !phases4) ? 512 : 256, cob = big == 0 ? 128 : big == 3 ? 32 : 64;
       const int64_t nyz = (int64_t)(a.cout_p / cob) * (phases4 ? 4 : 1);
       const int64_t nblocks = (a.npix + pxb - 1) / pxb * nyz;
       const int64_t rounds = nblocks / ncu[dev], last = nblocks - rounds * ncu[dev];

@@ -10,4 +10,4 @@ timeout -s KILL 120 rocprofv3 --output-format csv --pmc SQ_VALU_MFMA_BUSY_CYCLES
 timeout -s KILL 120 rocprofv3 --output-format csv --pmc FETCH_SIZE -d $O/fetch -o p -- python3 tools/bench_conv.py $NET $ROWS > $O/fetch.log 2>&1 &&
 timeout -s KILL 120 rocprofv3 --output-format csv --pmc WRITE_SIZE -d $O/write -o p -- python3 tools/bench_conv.py $NET $ROWS > $O/write.log 2>&1
 echo rc=$?
-for k in "halo_split_kernel<4, 1, 8, false, 2>" "halo_split_kernel<2, 2, 8, false, 2>" "halo_split_kernel<4, 1, 8, true, 2>" "halo_split_kernel<2, 2, 8, true, 2>" "halo_split_kernel<4, 1, 8, false, 3>" "halo_split_kernel<2, 2, 8, false, 3>" "halo_resident_kernel<8, 2>" "halo_resident_kernel<8, 3>" "conv_mfma_split_kernel<4, 2>" "conv_mfma_split_kernel<2, 2>" "conv_mfma_split_kernel<1, 2>" "conv_mfma_split_kernel<4, 3>" "cs_image_amax_kernel"; do echo "== $k"; python3 tools/pmc_kernel.py $O "$k"; done
+for k in "halo_split_kernel<4, 1, 8, false, 2>" "halo_split_kernel<2, 2, 4, false, 2>" "halo_split_kernel<2, 2, 8, false, 2>" "halo_split_kernel<4, 1, 8, true, 2>" "halo_split_kernel<2, 2, 8, true, 2>" "halo_split_kernel<4, 1, 8, false, 3>" "halo_split_kernel<2, 2, 8, false, 3>" "halo_resident_kernel<8, 2>" "halo_resident_kernel<8, 3>" "conv_mfma_split_kernel<4, 2>" "conv_mfma_split_kernel<2, 2>" "conv_mfma_split_kernel<1, 2>" "conv_mfma_split_kernel<4, 3>" "cs_image_amax_kernel"; do echo "== $k"; python3 tools/pmc_kernel.py $O "$k"; done

@@ -7,8 +7,10 @@
 //
 // Execution model: one kernel per layer over NHWC activations held in a per-handle workspace;
 // rows (images) are processed in chunks so that the workspace stays within a fixed budget.
-//   * convolutions / linear layers with cin, cout multiples of 32: implicit GEMM on the exact-f32
-//     matrix cores (v_mfma_f32_32x32x2_f32), cs_conv_mfma_kernel;
+//   * convolutions / linear layers with cin, cout multiples of 32: implicit GEMM on the matrix cores.  Arithmetic by
+//     the handle's / process's setting: exact f32 (v_mfma_f32_32x32x2_f32: cs_conv_mfma_kernel, cs_conv3x3_halo_kernel),
+//     the 3-term bf16 split, or (default) the 2-term fp16 split of the convolutions with one power-of-two operand scale
+//     per image (cs_conv3x3_halo_split_kernel, cs_conv3x3_halo_resident_kernel, cs_conv_mfma_split_kernel; TERMS);
 //   * everything else (first convolution from 1 channel, last convolution to 1-2 channels, the
 //     small linear layers): cs_conv_direct_kernel, one thread per output element;
 //   * the distribution parameterisation of VAE.create_distribution (irwg/models/vae.py:203-256),

@@ -1592,23 +1592,33 @@ __global__ void __launch_bounds__(256) cs_avgpool_kernel(const float* in, float*
 
 // F.interpolate(mode='nearest', size=...) over NHWC: src = min(floor(dst * (in/out)), in-1) with
 // the scale in float32, as torch computes it.
-// (Per-image maxima of the output are left to the reduction pass: one join per wavefront from this kernel's 10^5
-// blocks took four times the kernel's own time on the words of 2048 images.)
+// grid (slices, image groups): a block walks a slice of ONE image's output, so the per-image maximum of the output
+// (out_amax, or null; bits of |value|, zeroed by the caller) costs one join per wavefront and slice.  (One join per
+// wavefront of a flat one-element-per-thread grid, 10^5 blocks on the words of 2048 images, took four times the
+// kernel's own time.)
 __global__ void __launch_bounds__(256) cs_resize_kernel(const float* in, float* out, int64_t n, int hin, int win,
-                                                        int hout, int wout, int c) {
-  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= n * hout * wout * c) return;
-  const int ch = (int)(idx % c);
-  int64_t t = idx / c;
-  const int ow = (int)(t % wout);
-  t /= wout;
-  const int oh = (int)(t % hout);
-  const int64_t r = t / hout;
+                                                        int hout, int wout, int c, unsigned* out_amax) {
+  const int per = hout * wout * c;
   const float sh = (float)hin / (float)hout, sw = (float)win / (float)wout;
-  int ih = (int)floorf((float)oh * sh), iw = (int)floorf((float)ow * sw);
-  ih = ih < hin - 1 ? ih : hin - 1;
-  iw = iw < win - 1 ? iw : win - 1;
-  out[idx] = in[((r * hin + ih) * win + iw) * c + ch];
+  for (int64_t r = blockIdx.y; r < n; r += gridDim.y) {
+    float m = 0.0f;
+    for (int e = (int)blockIdx.x * 256 + (int)threadIdx.x; e < per; e += (int)gridDim.x * 256) {
+      const int ch = e % c;
+      const int t = e / c;
+      const int ow = t % wout, oh = t / wout;
+      int ih = (int)floorf((float)oh * sh), iw = (int)floorf((float)ow * sw);
+      ih = ih < hin - 1 ? ih : hin - 1;
+      iw = iw < win - 1 ? iw : win - 1;
+      const float v = in[((r * hin + ih) * win + iw) * c + ch];
+      out[r * per + e] = v;
+      m = fmaxf(m, fabsf(v));
+    }
+    if (out_amax) {
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+      if ((threadIdx.x & 63) == 0 && m > 0.0f) conv_amax_join(out_amax + r, __float_as_uint(m));
+    }
+  }
 }
 
 // ----------------------------------------------------------------------------------------
@@ -2140,6 +2150,10 @@ int launch_conv(const CsProgram& p, const CsLayer& L, const float* in, const flo
       a.wexp[0] = L.wexp;
       a.in_amax = in_amax;
     }
+    if (split && out_amax && g_conv_fused_amax && d.cout % 32 == 0 && !d.out_nchw) {  // generic kernel's store epilogue
+      a.out_amax = out_amax;
+      if (wrote_amax) *wrote_amax = true;
+    }
     return launch_conv_mfma(a, stream);
   }
   a.ksize = 2;
@@ -2164,6 +2178,10 @@ int launch_conv(const CsProgram& p, const CsLayer& L, const float* in, const flo
       }
       return launch_conv_mfma(a, stream);
     }
+  }
+  if (split && out_amax && g_conv_fused_amax && d.cout % 32 == 0 && !d.out_nchw) {  // the four launches join one table
+    a.out_amax = out_amax;
+    if (wrote_amax) *wrote_amax = true;
   }
   for (int ph = 0; ph < 4; ++ph) {
     a.ooh = ph >> 1; a.oow = ph & 1;
@@ -2542,8 +2560,12 @@ int cs_prog_launch(const CsMlpArgs& a, hipStream_t stream) {
         hipLaunchKernelGGL(cs_avgpool_kernel, dim3(blocks_for(rows * d.cin)), dim3(256), 0, stream, src, dst, rows,
                            d.hin * d.win, d.cin);
       } else {
-        hipLaunchKernelGGL(cs_resize_kernel, dim3(blocks_for(rows * d.hout * d.wout * d.cin)), dim3(256), 0, stream,
-                           src, dst, rows, d.hin, d.win, d.hout, d.wout, d.cin);
+        unsigned* oam = (any_half && wants[li] && g_conv_fused_amax) ? p->amax_ws + li * (size_t)p->ws_rows : nullptr;
+        const int per = d.hout * d.wout * d.cin;
+        const unsigned gx = (unsigned)std::max(1, std::min(8, (per + 2047) / 2048));  // 8+ elements per thread
+        hipLaunchKernelGGL(cs_resize_kernel, dim3(gx, (unsigned)std::min<int64_t>(rows, 32768)), dim3(256), 0, stream,
+                           src, dst, rows, d.hin, d.win, d.hout, d.wout, d.cin, oam);
+        if (oam) have[li] = 1;
       }
     }
     if (a.mode == CS_MLP_ENC)

@@ -836,7 +836,7 @@ __global__ void __launch_bounds__(64 * NW, 2) cs_conv3x3_halo_split_kernel(const
 // its slot swizzle, weights from a.w3h, operands of image n scaled by the power of two from in_amax[n], fetched with
 // the window rows).
 template <int NW, int TERMS = 3>
-__global__ void __launch_bounds__(64 * NW) cs_conv3x3_halo_resident_kernel(const CsConvArgs a, int NR, int NP, int nitems) {
+__global__ void __launch_bounds__(64 * NW, 2) cs_conv3x3_halo_resident_kernel(const CsConvArgs a, int NR, int NP, int nitems) {
   constexpr int NTHR = 64 * NW, RPP = NTHR / 8;
   constexpr int ROWB = 64 * TERMS, W_B = 2048 * TERMS, NPMAX = 6;
   constexpr int RS = 128 + 16;  // transposition row: 32 channels + padding
@@ -1800,6 +1800,7 @@ bool g_conv_fused_amax = getenv("CSVAE_NO_FUSED_AMAX") == nullptr;
 // block's prologue and epilogue run under the other's matrix instructions (Omniglot encoder 6.05 -> 5.89 ms, decoder
 // 7.51 -> 7.24 on one box; the same shape measured slower for the upsampling form, and 128-pixel 4-wave blocks at two per
 // CU for the 128+-channel layers 4 % slower: twice the weight stream per CU).  CSVAE_HALO_224=0: 512-pixel 8-wave blocks.
+bool g_resident_two = getenv("CSVAE_RESIDENT_ONE") == nullptr;  // measurements with one 8-wave workgroup per CU
 bool g_halo_224 = getenv("CSVAE_HALO_224") == nullptr || atoi(getenv("CSVAE_HALO_224")) != 0;
 // LDS bytes of cs_conv3x3_halo_split_kernel<CT, PT, NW>: three weight slots, the window, a row of zeros
 // (or, if larger, the epilogue's per-wave transposition regions)
@@ -1876,31 +1877,32 @@ int launch_conv_mfma(const CsConvArgs& a, hipStream_t stream) {
     hipLaunchKernelGGL(KERNEL_, dim3(gx, a.cout_p / (32 * CT_)), dim3(256), LDS_, stream, a, ##__VA_ARGS__);            \
   } while (0)
     if (same3 && a.cin == 32 && a.cout == 32 && !a.out_nchw && a.npix < ((int64_t)1 << 31)) {
-      // weights resident in LDS, persistent workgroups (cs_conv3x3_halo_resident_kernel)
-      constexpr int NW_ = 8;
+      // weights resident in LDS, persistent workgroups (cs_conv3x3_halo_resident_kernel).  fp16 split: 4-wave
+      // workgroups of 128-pixel items, two to a CU (74 KB of LDS each), whose phases -- matrix instructions, stores,
+      // staging of the next window -- interleave; bf16 split (96 KB at that shape): one 8-wave workgroup per CU.
       const bool half = a.w3h != nullptr && a.in_amax != nullptr;  // fp16 split
-      const int terms = half ? 2 : 3;
-      const int NR = 32 * NW_ + 2 * (a.win + 1), NP = (NR * 8 + 64 * NW_ - 1) / (64 * NW_);
-      const size_t lds = (size_t)9 * 2048 * terms + (((size_t)NR * 64 * terms + 256 + 1023) & ~(size_t)1023) + (size_t)NW_ * 32 * 144;
-      CS_REQUIRE(NP <= 6 && lds <= 160 * 1024, "halo window does not fit");
-      static bool attr_set[64] = {};
       static int ncu[64] = {};
-      if (!attr_set[dev]) {
-        CS_HIP(hipFuncSetAttribute((const void*)cs_conv3x3_halo_resident_kernel<NW_, 3>,
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        CS_HIP(hipFuncSetAttribute((const void*)cs_conv3x3_halo_resident_kernel<NW_, 2>,
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        CS_HIP(hipDeviceGetAttribute(&ncu[dev], hipDeviceAttributeMultiprocessorCount, dev));
-        attr_set[dev] = true;
-      }
-      const int nitems = (int)((a.npix + 32 * NW_ - 1) / (32 * NW_));
-      const int grid = nitems < ncu[dev] ? nitems : ncu[dev];
-      if (half)
-        hipLaunchKernelGGL((cs_conv3x3_halo_resident_kernel<NW_, 2>), dim3((unsigned)grid), dim3(64 * NW_), lds, stream, a, NR,
-                           NP, nitems);
-      else
-        hipLaunchKernelGGL((cs_conv3x3_halo_resident_kernel<NW_, 3>), dim3((unsigned)grid), dim3(64 * NW_), lds, stream, a, NR,
-                           NP, nitems);
+      if (!ncu[dev]) CS_HIP(hipDeviceGetAttribute(&ncu[dev], hipDeviceAttributeMultiprocessorCount, dev));
+#define CS_RESIDENT_LAUNCH(NW_, TM_, PER_CU_)                                                                                    \
+  do {                                                                                                                           \
+    const int NR = 32 * NW_ + 2 * (a.win + 1), NP = (NR * 8 + 64 * NW_ - 1) / (64 * NW_);                                        \
+    const size_t lds = (size_t)9 * 2048 * TM_ + (((size_t)NR * 64 * TM_ + 256 + 1023) & ~(size_t)1023) + (size_t)NW_ * 32 * 144; \
+    CS_REQUIRE(NP <= 6 && lds <= 160 * 1024, "halo window does not fit");                                                        \
+    static bool attr_set[64] = {};                                                                                               \
+    if (!attr_set[dev]) {                                                                                                        \
+      CS_HIP(hipFuncSetAttribute((const void*)cs_conv3x3_halo_resident_kernel<NW_, TM_>,                                         \
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                                       \
+      attr_set[dev] = true;                                                                                                      \
+    }                                                                                                                            \
+    const int nitems = (int)((a.npix + 32 * NW_ - 1) / (32 * NW_));                                                              \
+    const int grid = nitems < PER_CU_ * ncu[dev] ? nitems : PER_CU_ * ncu[dev];                                                  \
+    hipLaunchKernelGGL((cs_conv3x3_halo_resident_kernel<NW_, TM_>), dim3((unsigned)grid), dim3(64 * NW_), lds, stream, a, NR,    \
+                       NP, nitems);                                                                                              \
+  } while (0)
+      if (half && g_resident_two) CS_RESIDENT_LAUNCH(4, 2, 2);
+      else if (half) CS_RESIDENT_LAUNCH(8, 2, 1);
+      else CS_RESIDENT_LAUNCH(8, 3, 1);
+#undef CS_RESIDENT_LAUNCH
     } else if (same3 || phases4) {
       // fp16 split where the caller supplied its weights and the input's per-image maxima
       const bool half = a.w3h != nullptr && a.in_amax != nullptr;

@@ -42,6 +42,9 @@ WORKLOADS = {
     "miniboone": dict(D=43, Zd=32, H=256, nbe=5, nbd=2, K=4, R=1),
     "hepmass": dict(D=21, Zd=16, H=256, nbe=2, nbd=2, K=16, R=1),
     "gas": dict(D=8, Zd=16, H=256, nbe=2, nbd=2, K=16, R=1),
+    # more than 64 proposals per example (the multi-wave weights / resampling path): the MiniBooNE networks with
+    # 96 chains + 4 prior proposals, as configs/mnist_gmm/samples/lair_k100_* have them
+    "miniboone_k100": dict(D=43, Zd=32, H=256, nbe=5, nbd=2, K=96, R=4),
 }
 F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X exact-f32 matrix peak
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X dense bf16 matrix peak
@@ -391,10 +394,12 @@ def leg_acmwg_class(model, B, K, D, T, dev, flops_per_chain, arith, binary=False
 def extra_legs(args, arith, dev):
     legs = {}
     steps = max(5, args.steps // 2)
-    for name in ("hepmass", "gas"):
+    for name in ("hepmass", "gas", "miniboone_k100"):
         if name == args.workload:
             continue
         nb = WHOLE_SET_BATCH if args.batch == 65536 else args.batch   # the whole-test-set configurations: 131 072 examples per GPU
+        if name == "miniboone_k100":
+            nb = 4096   # 393 216 encoder rows, 409 600 decoder rows
         b = LairCabi(name, nb, 0, dev)
         el, evs = b.timed(steps, args.warmup)
         roof, kern = b.kernel_report(evs, arith)

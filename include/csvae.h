@@ -475,6 +475,9 @@ int cs_debug_set_workspace_budget(int64_t bytes);
  * example (I*K') in one launch, one wavefront per group of examples, and larger sets in three launches; with
  * on = 1 every size takes the three-launch path.  Returns the previous setting. */
 int cs_debug_force_large_resample(int on);
+/* Test hook (no counterpart in the reference): 1 keeps the scalar log-weight kernel of the path for more than 64
+ * proposals per example where its 16-byte-access form would run; both give the same bits. */
+int cs_debug_force_scalar_logw(int on);
 /* Test hook (no counterpart in the reference): launches of the fused MLP in the fp16 split of up to 512 row tiles run
  * in a kernel that gives a row tile to a workgroup and splits each layer's output features over its wavefronts;
  * mode 0 disables that kernel, 1 uses it for every launch it has an instance for, -1 restores the size rule.

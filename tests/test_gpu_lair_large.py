@@ -208,3 +208,30 @@ def test_yaml_driver_end_to_end_configs_with_many_chains(tmp_path, config, K, D,
         assert np.array_equal(imps[t][obs], truth[obs])
     # the chains move: resampling and fresh imputations change the missing entries every iteration
     assert not np.array_equal(imps[1][~obs], imps[T][~obs])
+
+
+@pytest.mark.parametrize("Zd,K,R,I", [(32, 96, 4, 1), (16, 130, 0, 1), (8, 70, 1, 2), (32, 300, 1, 1)])
+def test_log_weight_kernels_of_the_large_path_agree_bit_for_bit(Zd, K, R, I):
+    """The 16-byte-access log-weight kernel (latent in registers for Zd = 16 / 32, in LDS otherwise) computes the
+    terms of the scalar kernel in the same order: identical log-weights, statistics and imputations."""
+    from oracle import cs_oracle as O
+    from tests.helpers import seeded_inputs
+    from vae_conditional_sampling_amd import _lib
+    from vae_conditional_sampling_amd.sampling.vae_imputation import importance_resampling_gibbs_iteration
+    B, D = 7, 11
+    model = make_model(O.make_resfc_weights(D, 2 * Zd, 1, 64, 41), O.make_resfc_weights(Zd, 2 * D, 1, 64, 42))
+    X, M = seeded_inputs(B, K, D, 43)
+    X, M = X.cuda(), M.cuda()
+
+    def run():
+        return importance_resampling_gibbs_iteration(model, X, M, I, num_prior_replenish_proposals=R,
+                                                     rng=_lib.make_rng(9, 1, 0))
+    vec = [t.clone() if torch.is_tensor(t) else t for t in run()]
+    prev = _lib.lib().cs_debug_force_scalar_logw(1)
+    try:
+        ref = run()
+    finally:
+        _lib.lib().cs_debug_force_scalar_logw(prev)
+    for i in (0, 1, 3, 5, 7):
+        assert torch.equal(vec[i], ref[i]), i
+    assert torch.isfinite(vec[7]).all()

@@ -192,6 +192,7 @@ def lib():
     L.cs_gen_loglik_rows.argtypes = [vp, i32, vp, vp, i64, i32, i32, vp, vp]
     L.cs_debug_set_workspace_budget.argtypes = [i64]
     L.cs_debug_force_large_resample.argtypes = [i32]
+    L.cs_debug_force_scalar_logw.argtypes = [i32]
     L.cs_debug_set_narrow.argtypes = [i32]
     L.cs_set_mlp_arith.argtypes = [i32]
     L.cs_mlp_set_arith.argtypes = [vp, i32]

@@ -67,7 +67,15 @@ __device__ __forceinline__ void lse_add(float c, float& m, float& sum) {
 }
 __device__ __forceinline__ float lse_finish(float m, float sum) { return logf(sum) + m; }
 
+// test hook: 1 keeps the scalar log-weight kernel where the 16-byte form would run
+int g_logw_scalar = 0;
+
 }  // namespace
+
+extern "C" int cs_debug_force_scalar_logw(int on) {
+  g_logw_scalar = on ? 1 : 0;
+  return CS_OK;
+}
 
 // ----------------------------------------------------------------------------------------------------------
 // log w[i,b,k'] = log p(x_o | z) + log p(z) - log q_mix(z)            (weights.py:46-57, 69-85)
@@ -155,7 +163,7 @@ __global__ void __launch_bounds__(LG_TP) cs_lair_logw_large_kernel(const CsResam
           } else {
             for (int d = 0; d < Zd; ++d) {
               const float df = zr[d] - c0[d];
-              cj -= (df * df) * c1[d];
+              cj = __builtin_fmaf(-(df * df), c1[d], cj);   // spelled out: the 16-byte form below must round the same way
             }
             cj -= l_L[jj];
           }
@@ -447,6 +455,115 @@ __global__ void __launch_bounds__(256) cs_lair_impute_large_kernel(const CsResam
   cs_lair_impute_item(a, be, n, dq, src);
 }
 
+// The common case of the launch above -- Normal posteriors, every proposal under all K' components (dmis), Zd a
+// multiple of 4, 16-byte aligned q and Z -- with 16-byte accesses: a thread keeps its latent in registers (ZQ = Zd / 4
+// quads; ZQ = 0: any Zd, the latent in its LDS row), the staged components are read a quad of dimensions at a time
+// (one address per wavefront: a broadcast), two components run side by side so that their dependent sums overlap.
+// The same terms in the same order as the kernel above: the results are bit-identical.
+template <int ZQ>
+__global__ void __launch_bounds__(LG_TP) cs_lair_logw_large_vec_kernel(const CsResampleArgs a, int tiles) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x;
+  const int B = a.cfg.B, Zd = a.cfg.Zd, Kp = a.Kp, S = a.S;
+  const int Zq = Zd >> 2;
+  const int64_t b = blockIdx.x / tiles;
+  const int s = (int)(blockIdx.x - b * tiles) * LG_TP + tid;
+  const bool act = s < S;
+  const int ZS = Zd + 4;                       // row stride of the latents in LDS (ZQ = 0): 16-byte aligned rows whose
+                                               // 16-byte slots fall into different banks for 16 consecutive threads
+  float* l_z = lds;                            // [TP][ZS]  (ZQ = 0 only)
+  float* l_c0 = l_z + (ZQ == 0 ? LG_TP * ZS : 0);  // [TC][Zd]  loc
+  float* l_c1 = l_c0 + LG_TC * Zd;             // [TC][Zd]  1/(2 s^2)
+  float* l_c2 = l_c1 + LG_TC * Zd;             // [TC][Zd]  log s
+  float* l_L = l_c2 + LG_TC * Zd;              // [TC]      sum_d log s + Zd log sqrt(2 pi)
+  const int i_s = act ? s / Kp : 0, kp_s = act ? s - i_s * Kp : 0;
+  const int64_t rho = ((int64_t)i_s * B + b) * Kp + kp_s;
+  f32x4 zreg[ZQ > 0 ? ZQ : 1];
+  f32x4* zr = (f32x4*)(l_z + tid * ZS);
+  float pl = 0.0f;
+  if (act) {
+    const f32x4* zg = (const f32x4*)(a.b.Z + rho * Zd);
+    for (int dq = 0; dq < (ZQ > 0 ? ZQ : Zq); ++dq) {
+      const f32x4 z = zg[dq];
+      if (a.cfg.prior == CS_PRIOR_UNIFORM) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pl += (z[r] >= 0.0f && z[r] < 1.0f) ? 0.0f : -INFINITY;
+      } else {
+        pl += cs_stdnormal_logpdf(z.x); pl += cs_stdnormal_logpdf(z.y);
+        pl += cs_stdnormal_logpdf(z.z); pl += cs_stdnormal_logpdf(z.w);
+      }
+      if (ZQ > 0) zreg[dq] = z;
+      else zr[dq] = z;
+    }
+  }
+  float m = -INFINITY, sum = 0.0f;
+  // log-density of component jj of the staged tile at the thread's latent, summed over the dimensions in order
+  auto dens2 = [&](int jj, bool two, float& ca, float& cb) {
+    const f32x4* c0a = (const f32x4*)(l_c0 + jj * Zd);
+    const f32x4* c1a = (const f32x4*)(l_c1 + jj * Zd);
+    const f32x4* c0b = c0a + (two ? Zq : 0);
+    const f32x4* c1b = c1a + (two ? Zq : 0);
+    ca = 0.0f; cb = 0.0f;
+#pragma unroll
+    for (int dq = 0; dq < (ZQ > 0 ? ZQ : Zq); ++dq) {
+      const f32x4 z = ZQ > 0 ? zreg[dq] : zr[dq];
+      const f32x4 ma = c0a[dq], wa = c1a[dq], mb = c0b[dq], wb = c1b[dq];
+      float df;
+      df = z.x - ma.x; ca = __builtin_fmaf(-(df * df), wa.x, ca);
+      df = z.x - mb.x; cb = __builtin_fmaf(-(df * df), wb.x, cb);
+      df = z.y - ma.y; ca = __builtin_fmaf(-(df * df), wa.y, ca);
+      df = z.y - mb.y; cb = __builtin_fmaf(-(df * df), wb.y, cb);
+      df = z.z - ma.z; ca = __builtin_fmaf(-(df * df), wa.z, ca);
+      df = z.z - mb.z; cb = __builtin_fmaf(-(df * df), wb.z, cb);
+      df = z.w - ma.w; ca = __builtin_fmaf(-(df * df), wa.w, ca);
+      df = z.w - mb.w; cb = __builtin_fmaf(-(df * df), wb.w, cb);
+    }
+    ca -= l_L[jj];
+    cb -= l_L[jj + (two ? 1 : 0)];
+  };
+  for (int j0 = 0; j0 < Kp; j0 += LG_TC) {
+    const int tc = (Kp - j0) < LG_TC ? (Kp - j0) : LG_TC;
+    __syncthreads();   // the previous tile is consumed
+    const float* qb = a.b.q + (b * Kp + j0) * 2 * Zd;
+    for (int t = tid; t < tc * Zq; t += LG_TP) {
+      const int jj = cs_div(t, a.dZq), dq = t - jj * Zq;
+      const f32x4 loc = *(const f32x4*)(qb + (int64_t)jj * 2 * Zd + 4 * dq);
+      const f32x4 sc = *(const f32x4*)(qb + (int64_t)jj * 2 * Zd + Zd + 4 * dq);
+      f32x4 o1, o2;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        o1[r] = __builtin_amdgcn_rcpf(2.0f * (sc[r] * sc[r]));
+        o2[r] = cs_logf(sc[r]);
+      }
+      *(f32x4*)(l_c0 + jj * Zd + 4 * dq) = loc;
+      *(f32x4*)(l_c1 + jj * Zd + 4 * dq) = o1;
+      *(f32x4*)(l_c2 + jj * Zd + 4 * dq) = o2;
+    }
+    __syncthreads();
+    if (tid < tc) {
+      float Lj = 0.0f;
+      for (int d = 0; d < Zd; ++d) Lj += l_c2[tid * Zd + d];
+      l_L[tid] = Lj + (float)Zd * CS_LOG_SQRT_2PI;
+    }
+    __syncthreads();
+    if (act) {
+      int jj = 0;
+      for (; jj + 1 < tc; jj += 2) {
+        float ca, cb;
+        dens2(jj, true, ca, cb);
+        lse_add(ca, m, sum);
+        lse_add(cb, m, sum);
+      }
+      if (jj < tc) {
+        float ca, cb;
+        dens2(jj, false, ca, cb);
+        lse_add(ca, m, sum);
+      }
+    }
+  }
+  if (act) a.b.log_w[rho] = a.b.gen_ll[rho] + pl - (lse_finish(m, sum) - logf((float)Kp));
+}
+
 // ----------------------------------------------------------------------------------------------------------
 int cs_lair_resample_large(CsResampleArgs& a, hipStream_t stream) {
   const cs_lair_cfg& c = a.cfg;
@@ -466,7 +583,15 @@ int cs_lair_resample_large(CsResampleArgs& a, hipStream_t stream) {
     const int tiles = (S + LG_TP - 1) / LG_TP;
     CS_REQUIRE(B * tiles < (1ll << 31), "batch too large");
     const dim3 grid((unsigned)(B * tiles));
-    if (beta) {
+    const bool vec = !beta && uniform && (Zd & 3) == 0 && (((uintptr_t)a.b.q | (uintptr_t)a.b.Z) & 15) == 0 && !g_logw_scalar;
+    if (vec) {
+      a.dZq = cs_mkdiv(Zd >> 2);
+      const size_t ldsv = ((size_t)(Zd == 16 || Zd == 32 ? 0 : LG_TP * (Zd + 4)) + (size_t)3 * LG_TC * Zd + LG_TC) * 4;
+      CS_REQUIRE(ldsv <= 64 * 1024, "latent dimension too large for proposal sets of more than 64 per example");
+      if (Zd == 16) hipLaunchKernelGGL((cs_lair_logw_large_vec_kernel<4>), grid, dim3(LG_TP), ldsv, stream, a, tiles);
+      else if (Zd == 32) hipLaunchKernelGGL((cs_lair_logw_large_vec_kernel<8>), grid, dim3(LG_TP), ldsv, stream, a, tiles);
+      else hipLaunchKernelGGL((cs_lair_logw_large_vec_kernel<0>), grid, dim3(LG_TP), ldsv, stream, a, tiles);
+    } else if (beta) {
       if (uniform) hipLaunchKernelGGL((cs_lair_logw_large_kernel<true, true>), grid, dim3(LG_TP), lds, stream, a, tiles);
       else hipLaunchKernelGGL((cs_lair_logw_large_kernel<true, false>), grid, dim3(LG_TP), lds, stream, a, tiles);
     } else {

@@ -33,13 +33,18 @@ __device__ __forceinline__ float wsum(float v) {
   return v;
 }
 
-// ---- prepare: one thread per chain ----
-__global__ void __launch_bounds__(256) cs_acmwg_prepare_kernel(const CsAcmwgArgs a) {
-  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+// ---- prepare: one thread per (chain, quad of latent dimensions) ----
+// Quad 0 of a chain draws the history slot and writes the chain's flags; every quad of a chain that proposes from the
+// prior draws its own 4 normals (one counter-RNG block; with one thread per chain a block was evaluated once per
+// element, 32 in a row for a chain that took the prior, and set the launch's time at any batch size).
+__global__ void __launch_bounds__(256) cs_acmwg_prepare_kernel(const CsAcmwgArgs a, int ZQ) {
+  const int64_t gt = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int B = a.cfg.B, K = a.cfg.K, D = a.cfg.D, Zd = a.cfg.Zd;
+  const int64_t t = gt / ZQ;
+  const int q = (int)(gt - t * ZQ);
   if (t >= (int64_t)B * K) return;
   const int64_t grow = a.rng.row_offset * K + t;  // global chain row
-  if (!(a.cfg.flags & CS_MWG_PROPOSE_FROM_CURRENT)) {
+  if (q == 0 && !(a.cfg.flags & CS_MWG_PROPOSE_FROM_CURRENT)) {
     // uniform index among the available history entries (utils.py:219-237)
     int64_t bound = a.b.avail[t];
     if (bound < 1) bound = 1;
@@ -62,11 +67,18 @@ __global__ void __launch_bounds__(256) cs_acmwg_prepare_kernel(const CsAcmwgArgs
     const float u = a.b.u_prior ? a.b.u_prior[t] : cs_uniform_elem(a.rng, CS_STREAM_UPRIOR, grow, 0);
     up = u < (float)a.cfg.prior_mixture_probability;
     if (up) {
-      for (int d = 0; d < Zd; ++d)
-        a.b.z_alt[t * Zd + d] = a.b.z_prior ? a.b.z_prior[t * Zd + d] : cs_normal_elem(a.rng, CS_STREAM_ZPRIOR, grow, d);
+      const int d0 = 4 * q;
+      if (a.b.z_prior) {
+        for (int d = d0; d < d0 + 4 && d < Zd; ++d) a.b.z_alt[t * Zd + d] = a.b.z_prior[t * Zd + d];
+      } else {
+        uint32_t x[4];
+        cs_philox_block(a.rng, CS_STREAM_ZPRIOR, grow, (uint32_t)q, x);
+        const f32x4 n = cs_normal4(x);
+        for (int d = d0; d < d0 + 4 && d < Zd; ++d) a.b.z_alt[t * Zd + d] = n[d - d0];
+      }
     }
   }
-  a.b.use_prior[t] = up;
+  if (q == 0) a.b.use_prior[t] = up;
 }
 
 // ---- accept: LP lanes per chain (LP a power of two, 64 / LP chains per wavefront) ----
@@ -415,7 +427,8 @@ extern "C" int cs_acmwg_step(const cs_mlp_t* enc, const cs_mlp_t* dec, const cs_
   a.cfg = *c; a.b = *b; a.rng = cs_make_philox(rng);
   const int64_t chains = (int64_t)c->B * c->K;
   if (use_hist || mix) {
-    hipLaunchKernelGGL(cs_acmwg_prepare_kernel, dim3((unsigned)((chains + 255) / 256)), dim3(256), 0, st, a);
+    const int ZQ = (c->Zd + 3) / 4;
+    hipLaunchKernelGGL(cs_acmwg_prepare_kernel, dim3((unsigned)((chains * ZQ + 255) / 256)), dim3(256), 0, st, a, ZQ);
     CS_HIP(hipGetLastError());
   }
   CsMlpArgs e;

@@ -379,6 +379,19 @@ class TestVAESamplerBase(HyperparametersMixin):
         return out
 
 
+def _means_of_three(a, b, c):
+    """Means of three per-example statistics.  The iteration returns them as consecutive rows of one workspace
+    array: one reduction launch then instead of three (at 65 536 examples the three launches were 3 % of a LAIR
+    iteration)."""
+    n = a.numel()
+    if (a.dim() == 1 and a.is_contiguous() and b.is_contiguous() and c.is_contiguous() and b.numel() == n and c.numel() == n
+            and a.untyped_storage().data_ptr() == b.untyped_storage().data_ptr() == c.untyped_storage().data_ptr()
+            and b.storage_offset() == a.storage_offset() + n and c.storage_offset() == a.storage_offset() + 2 * n):
+        m = torch.as_strided(a, (3, n), (n, 1), a.storage_offset()).mean(dim=1)
+        return m[0], m[1], m[2]
+    return a.mean(), b.mean(), c.mean()
+
+
 def _final_resampling(self, proposals, X_true, M, num_samples):
     """Categorical over all stored proposals of every example, ``n`` draws, decode in one launch,
     sample and set the observed values (test_step_vae_sampling.py:1991-2032, 2151-2185).
@@ -623,12 +636,13 @@ class TestVAELatentAdaptiveImportanceResampling(TestVAESamplerBase):
         if hp.store_norm_log_weights:
             all_norm_log_weights.append(norm_log_weights.clone())
 
+        ess_mean, tess_mean, perp_mean = _means_of_three(ess, transformed_ess, perplexity)
         yield {'X': X,
                'Z': latents,
-               'is_ess': ess.mean(),
+               'is_ess': ess_mean,
                'is_ess_not_reduced': ess,
-               'transformed_ess': transformed_ess.mean(),
-               'perplexity': perplexity.mean(),
+               'transformed_ess': tess_mean,
+               'perplexity': perp_mean,
                'total_num_props': total_num_props,
                'acceptance_x': 1.0,
                }

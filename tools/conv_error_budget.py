@@ -3,7 +3,7 @@ float64 evaluation, and how far the GPU results are from the reference's recorde
 
     python tools/conv_error_budget.py            # on a GPU box; prints a table and writes JSON to stdout's last line
 
-For every network of tests/helpers.CONV_NETS and both arithmetics of the matrix kernels it reports
+For every network of tests/helpers.CONV_NETS and the three float32-equivalent arithmetics of the matrix kernels it reports
 max |a - b| / (|b| + 1) of
   gpu vs f64     the GPU forward against the float64 evaluation of the oracle's functions,
   cpu32 vs f64   torch's CPU float32 forward (what the reference computes) against the same,
@@ -43,7 +43,7 @@ def main():
         with torch.no_grad():
             e64, d64 = OC.resnet_encoder_forward(to64(enc_w), x.double()), OC.resnet_decoder_forward(to64(dec_w), z.double())
             e32, d32 = OC.resnet_encoder_forward(enc_w, x), OC.resnet_decoder_forward(dec_w, z)
-        for arith in ("f32", "bf16x3"):
+        for arith in ("f32", "bf16x3", "f16x2"):
             prev = _lib.set_mlp_arith(arith)
             try:
                 model = make_conv_model(net, enc_w, dec_w, "normal", "normal" if net.startswith("gmm") else "bern")

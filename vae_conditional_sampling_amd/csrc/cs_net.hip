@@ -1899,7 +1899,7 @@ int launch_conv_mfma(const CsConvArgs& a, hipStream_t stream) {
     hipLaunchKernelGGL((cs_conv3x3_halo_resident_kernel<NW_, TM_>), dim3((unsigned)grid), dim3(64 * NW_), lds, stream, a, NR,    \
                        NP, nitems);                                                                                              \
   } while (0)
-      if (half && g_resident_two) CS_RESIDENT_LAUNCH(4, 2, 2);
+      if (half && g_resident_two && a.win + 1 <= 32) CS_RESIDENT_LAUNCH(4, 2, 2);   // wider images: the window needs 8 waves to stage
       else if (half) CS_RESIDENT_LAUNCH(8, 2, 1);
       else CS_RESIDENT_LAUNCH(8, 3, 1);
 #undef CS_RESIDENT_LAUNCH
@@ -1909,10 +1909,13 @@ int launch_conv_mfma(const CsConvArgs& a, hipStream_t stream) {
       // one 8-wave block per CU (two waves per SIMD); 64-channel layers give a wavefront two pixel tiles so
       // that a weight fragment feeds 12 matrix instructions
       const int big = a.cout_p % 128 == 0 ? 0 : a.cout_p % 64 == 0 ? (halo3_lds(2, 2, 8, a.win) <= 160 * 1024 ? 1 : 2) : 3;
+      // same-size 64-channel layers under the fp16 split: 4-wave blocks, two to a CU (images up to 31 wide: 4 waves stage
+      // a window of at most 320 rows in CS_HALO_NPMAX passes)
+      const bool two_per_cu = half && g_halo_224 && !phases4 && a.win + 1 <= 32;
       auto halo = [&](const CsConvArgs& a, bool tail) -> int {  // `a` of the macros: this launch's part of the images
         if (tail) CS_HALO3_LAUNCH(1, 1, 4);
         else if (big == 0) CS_HALO3_LAUNCH(4, 1, 8);
-        else if (big == 1 && half && g_halo_224 && !phases4) CS_HALO3_LAUNCH_(2, 2, 4, false, 2);
+        else if (big == 1 && two_per_cu) CS_HALO3_LAUNCH_(2, 2, 4, false, 2);
         else if (big == 1) CS_HALO3_LAUNCH(2, 2, 8);
         else if (big == 2) CS_HALO3_LAUNCH(2, 1, 8);
         else CS_HALO3_LAUNCH(1, 2, 4);
@@ -1925,7 +1928,7 @@ int launch_conv_mfma(const CsConvArgs& a, hipStream_t stream) {
       // spread over all CUs and whose matrix-instruction chains are an eighth as long.
       static int ncu[64] = {};
       if (!ncu[dev]) CS_HIP(hipDeviceGetAttribute(&ncu[dev], hipDeviceAttributeMultiprocessorCount, dev));
-      const int pxb = big == 1 && !(half && g_halo_224 && !phases4) ? 512 : 256, cob = big == 0 ? 128 : big == 3 ? 32 : 64;
+      const int pxb = big == 1 && !two_per_cu ? 512 : 256, cob = big == 0 ? 128 : big == 3 ? 32 : 64;
       const int64_t nyz = (int64_t)(a.cout_p / cob) * (phases4 ? 4 : 1);
       const int64_t nblocks = (a.npix + pxb - 1) / pxb * nyz;
       const int64_t rounds = nblocks / ncu[dev], last = nblocks - rounds * ncu[dev];

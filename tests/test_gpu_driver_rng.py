@@ -11,6 +11,11 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _host(series):
+    """A batch's point-wise diagnostic series as a numpy array (a one-process run keeps it in device memory)."""
+    return series.cpu().numpy() if torch.is_tensor(series) else np.asarray(series)
+
+
 def test_philox_uniforms_are_bit_exact_with_the_c_restatement():
     from oracle import c_binding
     from vae_conditional_sampling_amd import _lib
@@ -87,7 +92,7 @@ def test_yaml_driver_end_to_end_lair_and_acmwg(tmp_path):
     assert all(0 < e <= 5 for e in outs[0]["is_ess"])
     # the configuration enables the RMSE / MAE / latent-Wasserstein diagnostics: [T, B, K] per batch
     for name in ("rmse", "mae", "latent_wass"):
-        v = outs[0][f"imp_metric/{name}"]
+        v = _host(outs[0][f"imp_metric/{name}"])
         assert v.shape == (6, 64, 4) and np.isfinite(v).all() and (v >= 0).all()
     ms = np.load(os.path.join(tester.out_dir, "metrics_summary.npz"))
     assert ms["rmse__mean__test"].shape == (6,) and ms["rmse__q0.5__test"].shape == (6,)
@@ -95,7 +100,7 @@ def test_yaml_driver_end_to_end_lair_and_acmwg(tmp_path):
     # cross-check one entry of the RMSE against the stored imputations
     imp, tx, mk = f0["imputations"][3], f0["true_X"], f0["masks"]
     ref = np.sqrt((((imp - tx) ** 2) * ~mk).sum(-1) / np.maximum((~mk).sum(-1), 1))
-    assert np.allclose(outs[0]["imp_metric/rmse"][2], ref, rtol=1e-5, atol=1e-6)
+    assert np.allclose(_host(outs[0]["imp_metric/rmse"])[2], ref, rtol=1e-5, atol=1e-6)
 
     cfg = driver.load_config(os.path.join(ROOT, "configs/uci_miniboone/sampling_u50/acmwg_k5_005prior_irwg_warmup.yaml"),
                              common + ["test_class.init_args.num_pseudo_warmup_iterations=2",
@@ -133,7 +138,7 @@ def test_yaml_driver_whole_dataset_configs_k16(tmp_path, dataset, D):
     assert f1["imputations"].shape == (1, B0, 5, D) and np.isfinite(f1["imputations"]).all()
     assert all(0 < e <= 17 for e in outs[0]["is_ess"])
     for name in ("rmse", "mae"):
-        v = outs[0][f"imp_metric/{name}"]
+        v = _host(outs[0][f"imp_metric/{name}"])
         assert v.shape == (7, B0, 16) and np.isfinite(v).all()
 
 

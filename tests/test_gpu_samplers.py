@@ -187,3 +187,37 @@ def test_imputation_diagnostics_match_reference_golden():
     assert_close(IM.imputation_mae_metric(X, Xt, M), fx["mae"], "mae")
     assert_close(IM.imputation_latent_wass(X, Xt, model), fx["latent_wass"], "latent_wass")
     assert float(IM.imputation_rmse_metric(X, Xt, M)[0].abs().max()) == 0.0   # fully observed example
+
+
+@pytest.mark.parametrize("B,K,D", [(1, 1, 1), (37, 5, 21), (300, 16, 21), (129, 1, 8), (50, 3, 43), (9, 7, 64),
+                                   (11, 4, 65), (6, 2, 784), (2000, 16, 6)])
+def test_imputation_errors_over_shapes(B, K, D):
+    """Both error kernels (rows tiled through LDS up to 64 features, a wavefront per row beyond) against the
+    formula of irwg/sampling/imputation_metrics.py:85-102 / :133-143 in float64: ragged last tiles, tiles that
+    start inside an example, fully observed examples (count 0 -> 1), and a NaN truth at a missing entry."""
+    from vae_conditional_sampling_amd.sampling import imputation_metrics as IM
+    g = torch.Generator().manual_seed(B * 1000 + K * 10 + D)
+    X = torch.randn(B, K, D, generator=g)
+    Xt = torch.randn(B, 1, D, generator=g)
+    M = torch.rand(B, 1, D, generator=g) < 0.5
+    M[0] = True
+    if B > 3 and D > 1:
+        M[3, 0, 1] = False
+        Xt[3, 0, 1] = float("nan")
+    miss = (~M).double()
+    cnt = miss.sum(-1).clamp_min(1.0)
+    d = X.double() - Xt.double()
+    rmse = ((d * d * miss).sum(-1) / cnt).sqrt()
+    mae = ((d.abs() * miss).sum(-1) / cnt)
+    Xc, Xtc, Mc = X.cuda(), Xt.cuda(), M.cuda()
+    r, a = IM.imputation_rmse_metric(Xc, Xtc, Mc).cpu().double(), IM.imputation_mae_metric(Xc, Xtc, Mc).cpu().double()
+    assert torch.equal(r.isnan(), rmse.isnan()) and torch.equal(a.isnan(), mae.isnan())
+    ok = ~rmse.isnan()
+    assert torch.allclose(r[ok], rmse[ok], rtol=2e-6, atol=1e-7)   # float32 sums of <= 784 terms
+    assert torch.allclose(a[ok], mae[ok], rtol=2e-6, atol=1e-7)
+    assert float(r[0].abs().max()) == 0.0
+    # both results of one launch equal the separate ones
+    both_r, both_a = torch.empty(B, K, device="cuda"), torch.empty(B, K, device="cuda")
+    IM.imputation_errors(Xc, IM.PreparedTruth(Xtc, Mc, Xc), rmse=both_r, mae=both_a)
+    assert torch.equal(both_r.cpu().double().nan_to_num(-1), r.nan_to_num(-1))
+    assert torch.equal(both_a.cpu().double().nan_to_num(-1), a.nan_to_num(-1))

@@ -40,6 +40,56 @@ __global__ void __launch_bounds__(256) cs_imputation_error_kernel(const float* X
   }
 }
 
+// Narrow data (D <= 64, the tabular sets): a wavefront per row would leave most lanes idle and every row's
+// load a partial line.  A block of TR threads takes TR consecutive rows: their TR*D values are one contiguous
+// run, fetched with whole-line loads into LDS (row stride DS odd, so the per-row walk below hits TR different
+// banks), as are the true values and the masks of the examples the rows belong to; then one thread per row.
+// The sum over d runs in order of d.
+template <int TR>
+__global__ void __launch_bounds__(TR) cs_imputation_error_tile_kernel(const float* X, const float* Xt, const uint8_t* M,
+                                                                      int64_t rows, int K, int D, int DS, int nb_max,
+                                                                      float* rmse, float* mae) {
+  extern __shared__ float lds[];
+  float* l_x = lds;                  // [TR][DS]
+  float* l_t = l_x + TR * DS;        // [nb_max][DS] true values
+  float* l_m = l_t + nb_max * DS;    // [nb_max][DS] 1 = missing
+  const int tid = threadIdx.x;
+  const int64_t row0 = (int64_t)blockIdx.x * TR;
+  const int nr = (int)((rows - row0) < TR ? (rows - row0) : TR);
+  const int64_t b0 = row0 / K;
+  const int nb = (int)((row0 + nr - 1) / K - b0) + 1;
+  const float* xs = X + row0 * D;
+  for (int i = tid; i < nr * D; i += TR) {
+    const int r = i / D, d = i - r * D;
+    l_x[r * DS + d] = xs[i];
+  }
+  const float* ts = Xt + b0 * D;
+  const uint8_t* ms = M + b0 * D;
+  for (int i = tid; i < nb * D; i += TR) {
+    const int r = i / D, d = i - r * D;
+    l_t[r * DS + d] = ts[i];
+    l_m[r * DS + d] = ms[i] ? 0.0f : 1.0f;
+  }
+  __syncthreads();
+  if (tid >= nr) return;
+  const int64_t row = row0 + tid;
+  const int bl = (int)(row / K - b0);
+  const float* x = l_x + tid * DS;
+  const float* t = l_t + bl * DS;
+  const float* m = l_m + bl * DS;
+  float se = 0.0f, ae = 0.0f, cnt = 0.0f;
+  for (int d = 0; d < D; ++d) {
+    const float miss = m[d];
+    const float df = x[d] - t[d];
+    se += df * df * miss;
+    ae += fabsf(df) * miss;
+    cnt += miss;
+  }
+  if (cnt == 0.0f) cnt = 1.0f;
+  if (rmse) rmse[row] = sqrtf(se / cnt);
+  if (mae) mae[row] = ae / cnt;
+}
+
 // W[b,k] = sum_z (mu_i - mu_t)^2 + sum_z (var_i + var_t - 2 sqrt(var_i var_t)) between the Gaussian
 // posteriors of the imputed and the true datapoint; q rows are (loc | scale).
 __global__ void __launch_bounds__(256) cs_latent_wass_kernel(const float* q_imp, const float* q_true, int64_t rows, int K,
@@ -67,8 +117,17 @@ extern "C" int cs_imputation_errors(const float* X, const float* X_true, const u
   CS_REQUIRE(B >= 0 && K >= 1 && D >= 1, "bad sizes");
   const int64_t rows = B * K;
   if (rows == 0) return CS_OK;
-  hipLaunchKernelGGL(cs_imputation_error_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, X,
-                     X_true, M, rows, K, D, rmse, mae);
+  if (D <= 64) {
+    constexpr int TR = 128;
+    const int DS = D | 1;
+    const int nb_max = (TR + K - 2) / K + 1;   // examples that TR consecutive rows can belong to
+    const size_t lds = (size_t)(TR + 2 * nb_max) * DS * sizeof(float);
+    hipLaunchKernelGGL(cs_imputation_error_tile_kernel<TR>, dim3((unsigned)((rows + TR - 1) / TR)), dim3(TR), lds,
+                       (hipStream_t)stream, X, X_true, M, rows, K, D, DS, nb_max, rmse, mae);
+  } else {
+    hipLaunchKernelGGL(cs_imputation_error_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, X,
+                       X_true, M, rows, K, D, rmse, mae);
+  }
   CS_HIP(hipGetLastError());
   return CS_OK;
 }

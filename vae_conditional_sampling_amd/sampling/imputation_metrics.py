@@ -80,7 +80,8 @@ def imputation_latent_wass(X_imp, X_true, vae, *, q_true=None, out=None):
 
 def pointwise_summary(values, quantiles, device=None):
     """Per-iteration summary of a point-wise metric over the whole test set (the aggregation of
-    irwg/sampling/test_step_vae_sampling.py:824-858): ``values`` is the list of per-batch arrays ``[t, n_b, k]``;
+    irwg/sampling/test_step_vae_sampling.py:824-858): ``values`` is the list of per-batch series ``[t, n_b, k]``
+    (numpy arrays or tensors on any device);
     returns ``(mean[t], std[t], quant[len(quantiles), t])`` where mean / std are taken over the chains k of the mean
     over the data and the quantiles over all (n k) values of an iteration, numpy's default (linear) interpolation.
 
@@ -105,7 +106,7 @@ def pointwise_summary(values, quantiles, device=None):
     step = max(1, (1 << 27) // max(m, 1))          # <= 512 MiB of float32 per chunk
     for t0 in range(0, T, step):
         t1 = min(T, t0 + step)
-        x = torch.cat([torch.from_numpy(np.ascontiguousarray(v[t0:t1])) for v in values], dim=1).to(dev, torch.float32)
+        x = torch.cat([torch.as_tensor(v[t0:t1]).to(dev, torch.float32) for v in values], dim=1)
         over_data = x.mean(dim=1)                  # [tc, k]
         mean[t0:t1] = over_data.mean(dim=1).cpu().numpy()
         std[t0:t1] = (over_data.std(dim=1, unbiased=True) if K != 1 else torch.ones(t1 - t0, device=dev)).cpu().numpy()

@@ -204,6 +204,17 @@ class TestVAESamplerBase(HyperparametersMixin):
         else:
             writer.submit(path, **arrays)
 
+    def _keep_pointwise(self, series):
+        """Where a batch's point-wise diagnostic series [t, n_b, k] waits for the end of the epoch.  A one-process
+        run leaves it in device memory, where test_epoch_end reduces it (a whole UCI test set at 16 chains and 600
+        iterations is 13 GB for two metrics: moving that to the host and back took a third as long as sampling it);
+        it goes to the host as a numpy array when ranks will exchange it, or when the device is short of room."""
+        if self.collector is None and series.is_cuda:
+            free, _ = torch.cuda.mem_get_info(series.device)
+            if free > 8 * series.numel() * series.element_size():
+                return series
+        return series.cpu().numpy()
+
     def on_test_batch_start(self, batch: Any, batch_idx: int, dataloader_idx: int = 0) -> None:
         pass
 
@@ -372,7 +383,7 @@ class TestVAESamplerBase(HyperparametersMixin):
                            masks=M.cpu().numpy(), data_idx=np.asarray(I.cpu() if torch.is_tensor(I) else I))
         out = {k: [float(v) for v in vals] for k, vals in metrics.items()}   # device scalars: read once, here
         for name, buf in point.items():
-            out[f'imp_metric/{name}'] = buf[:t + 1].cpu().numpy()
+            out[f'imp_metric/{name}'] = self._keep_pointwise(buf[:t + 1])
         for key, value in out.items():
             self.metrics[key].append(value)
         self.metrics['num_X'].append(X_true.shape[0])

@@ -259,6 +259,30 @@ typedef struct {
 int cs_lair_run(const cs_mlp_t* enc, const cs_mlp_t* dec, const cs_lair_cfg* cfg, const cs_lair_bufs* b,
                 const cs_rng* rng, int32_t T, const cs_lair_run_out* out, void* stream);
 
+/* What the harness of test_step does with the chains after every iteration (test_step_vae_sampling.py:386-391
+ * keeps the imputations, :431-445 computes the diagnostics), done by the run itself so that the harness need not
+ * come back to the host between iterations.  After iteration t of a run:
+ *   X_store[t]    = the imputations X[B,K,D]                                   (NULL: not kept)
+ *   rmse_store[t] / mae_store[t] = cs_imputation_errors(X, X_true, M)          (NULL: not computed)
+ *   wass_store[t] = cs_latent_wasserstein(encoder posterior of X, q_true)      (NULL: not computed; Gaussian
+ *                   posteriors only; q_work[B,K,2,Zd] is the workspace of the encoder pass, q_true[B,2,Zd] the
+ *                   posterior of the true data, encoded once by the caller)
+ * each store holding T blocks of the per-iteration shape [B,K]. */
+typedef struct {
+  float* X_store;
+  const float* X_true; /* [B,D]; with rmse_store / mae_store */
+  float* rmse_store;
+  float* mae_store;
+  const float* q_true;
+  float* q_work;
+  float* wass_store;
+} cs_run_observe;
+/* cs_lair_run with the harness's per-iteration work (obs may be NULL: cs_lair_run).  Needs in-place imputation
+ * of all K chains (b->X_out NULL, cfg->K_impute 0 or K). */
+int cs_lair_run_observed(const cs_mlp_t* enc, const cs_mlp_t* dec, const cs_lair_cfg* cfg, const cs_lair_bufs* b,
+                         const cs_rng* rng, int32_t T, const cs_lair_run_out* out, const cs_run_observe* obs,
+                         void* stream);
+
 /* ---------------------------------------------------------------------------------------
  * AC-MWG (test_step_vae_sampling.py:1512-1768).  The imputation history
  * (ImputationHistoryQueue_with_restrictedavailability, irwg/sampling/utils.py:83-237) is a
@@ -335,6 +359,22 @@ int cs_acmwg_init_state(const cs_mlp_t* enc, const cs_mlp_t* dec, const cs_acmwg
  * into slot (hist_tail+1) % hist_len.  After the call the caller advances its tail/full. */
 int cs_acmwg_step(const cs_mlp_t* enc, const cs_mlp_t* dec, const cs_acmwg_cfg* cfg, const cs_acmwg_bufs* b,
                   const cs_rng* rng, void* stream);
+/* T MWG steps in one call: the loop of the samplers (:1221-1280, :1666-1766) for callers that need nothing on
+ * the host between steps.  Step t is exactly cs_acmwg_step with rng->iteration + t and the history scalars the
+ * reference's queue would hold then: hist_tail advances by one slot per step (mod hist_len) and hist_full turns 1
+ * when the tail reaches the last slot (utils.py:41-44); the caller advances its own scalars T times afterwards.
+ * With `out`, step t writes accepted / log_accept / slots into block t of the stores [T,B,K] (a NULL store leaves
+ * the buffer of `b` in use, overwritten every step) and copies the chain latents Z_old into Z_store[t] ([T,B,K,Zd]).
+ * Injected draws in `b`, when not NULL, hold T consecutive blocks of their per-step shapes.  `obs` as in
+ * cs_lair_run_observed. */
+typedef struct {
+  uint8_t* accepted_store;
+  float* log_accept_store;
+  int64_t* slots_store;
+  float* Z_store;
+} cs_acmwg_run_out;
+int cs_acmwg_run(const cs_mlp_t* enc, const cs_mlp_t* dec, const cs_acmwg_cfg* cfg, const cs_acmwg_bufs* b,
+                 const cs_rng* rng, int32_t T, const cs_acmwg_run_out* out, const cs_run_observe* obs, void* stream);
 /* enqueue_batch (utils.py:101-113): ages the counters when the ring was already full, then
  * writes X[B,K,D] into slot new_tail.  With was_full = 0 (avail may then be NULL) it is the
  * enqueue of the plain ImputationHistoryQueue of LAIR (utils.py:14-16). */

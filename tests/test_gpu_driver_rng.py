@@ -172,10 +172,11 @@ def test_sharded_driver_runs_reassemble_the_one_process_artifacts(tmp_path, conf
             assert a[k].dtype == b[k].dtype and np.array_equal(a[k], b[k]), f"{name}[{k}] differs between the runs"
 
 
-def test_sampler_runs_unobserved_stretches_in_one_call_with_identical_results(tmp_path):
-    """With only the last iterations stored and no per-iteration diagnostics the LAIR sampler runs the stretches
-    in between through cs_lair_run; stored imputations, final-resampling imputations and the ESS series must equal
-    those of the step-by-step run (bit for bit for the chain, to rounding for the batch means)."""
+def test_sampler_runs_stretches_in_one_call_with_identical_results(tmp_path):
+    """Under the harness the LAIR sampler runs max_iterations_per_call iterations per library call (cs_lair_run_observed);
+    stored imputations, final-resampling imputations and the ESS series must equal those of the step-by-step run
+    (bit for bit for the chain, to rounding for the batch means).  Here: only the last iterations stored, no
+    per-iteration diagnostics."""
     from vae_conditional_sampling_amd import driver
     from vae_conditional_sampling_amd.sampling import test_step_vae_sampling as TS
     over = ["data.synthetic_num_test=150", "data.num_first_datapoints_test=70", "data.batch_size=64",
@@ -202,7 +203,7 @@ def test_sampler_runs_unobserved_stretches_in_one_call_with_identical_results(tm
             TS.engine.lair_run = orig_run
         files = {n: dict(np.load(os.path.join(tester.out_dir, n))) for n in sorted(os.listdir(tester.out_dir)) if n.endswith(".npz")}
         res.append((files, outs))
-    assert not [c for c in calls if c[0] == 1] and [c[1] for c in calls if c[0] == 8][:3] == [8, 8, 6]   # 21 unread states, each call ends at most at the first state that is read
+    assert not [c for c in calls if c[0] == 1] and [c[1] for c in calls if c[0] == 8][:3] == [8, 8, 7]   # 23 iterations
     (f1, o1), (f8, o8) = res
     assert sorted(f1) == sorted(f8) and "irwg_imputations_after_final_resampling_1.npz" in f1
     for n in f1:
@@ -215,9 +216,9 @@ def test_sampler_runs_unobserved_stretches_in_one_call_with_identical_results(tm
     np.testing.assert_allclose(o1[0]["is_ess"], o8[0]["is_ess"], rtol=1e-6)
 
 
-def test_sampler_batches_the_iterations_between_stored_ones(tmp_path):
-    """store_every_n_iterations = 10 with every stored iteration kept: iteration 0 is stored, so the first step is a
-    single one, and the nine iterations up to the next stored one run in one library call, again and again."""
+def test_sampler_keeps_the_stored_iterations_of_a_stretch(tmp_path):
+    """store_every_n_iterations = 10: all 31 iterations run in one library call, which keeps every iteration's
+    imputations for the harness to pick the stored ones (0, 10, 20, 30) from."""
     from vae_conditional_sampling_amd import driver
     from vae_conditional_sampling_amd.sampling import test_step_vae_sampling as TS
     cfg = driver.load_config(os.path.join(ROOT, "configs/uci_miniboone/sampling_u50/lair_k4_dmis_gr_mult_1replenish.yaml"),
@@ -233,9 +234,66 @@ def test_sampler_batches_the_iterations_between_stored_ones(tmp_path):
         tester, outs = driver.run(cfg)
     finally:
         TS.engine.lair_run = orig_run
-    assert len(calls) >= 3 and sum(calls) >= 24, calls
+    assert calls == [31], calls
     f0 = np.load(os.path.join(tester.out_dir, "imputations_0.npz"))
-    assert f0["imputations"].shape[1:] == (40, 4, 43) and np.isfinite(f0["imputations"]).all()
+    assert f0["imputations"].shape == (1 + 4, 40, 4, 43) and np.isfinite(f0["imputations"]).all()
+    obs = np.broadcast_to(f0["masks"], (40, 4, 43))
+    assert all(np.array_equal(f0["imputations"][i][obs], np.broadcast_to(f0["true_X"], (40, 4, 43))[obs]) for i in range(5))
+    assert not np.array_equal(f0["imputations"][1], f0["imputations"][2])
+
+
+@pytest.mark.parametrize("config,extra,batches", [
+    ("configs/uci_miniboone/sampling_u50/lair_k4_dmis_gr_mult_1replenish.yaml", ["test_class.init_args.num_iterations=21"], 2),
+    ("configs/uci_miniboone/sampling_u50/acmwg_k5_005prior_irwg_warmup.yaml",
+     ["test_class.init_args.num_pseudo_warmup_iterations=3", "test_class.init_args.num_mwg_iterations=19"], 2),
+    ("configs/uci_miniboone/sampling_u50/acmwg_k5_005prior_irwg_warmup.yaml",
+     ["test_class.class_path=irwg.sampling.test_step_vae_sampling.TestVAEMetropolisWithinGibbs",
+      "test_class.init_args.prior_mixture_probability=null", "test_class.init_args.enqueue_allwarmup_samples_to_history=null",
+      "test_class.init_args.warmup_method=pseudo_gibbs", "test_class.init_args.num_pseudo_warmup_iterations=2",
+      "test_class.init_args.num_mwg_iterations=11"], 1)])
+def test_observed_runs_equal_single_steps_with_all_diagnostics(tmp_path, config, extra, batches):
+    """The published configurations keep every iteration and compute RMSE / MAE / latent distance on each: run
+    8 iterations per library call (the run keeps the imputations and computes the diagnostics itself) against one
+    step per call (the harness does).  Every artefact and every diagnostic must be identical bit for bit; batch
+    means of the acceptance / ESS series to rounding."""
+    from vae_conditional_sampling_amd import driver
+    from vae_conditional_sampling_amd.sampling import test_step_vae_sampling as TS
+    over = ["data.synthetic_num_test=100", f"data.num_first_datapoints_test={40 * batches}", "data.batch_size=40"] + extra
+    over = [o for o in over if not o.endswith("=null")]
+    drop = [o.split("=")[0].rsplit(".", 1)[1] for o in extra if o.endswith("=null")]
+    res = []
+    for cap in (1, 8):
+        cfg = driver.load_config(os.path.join(ROOT, config), over + [f"trainer.default_root_dir={tmp_path / str(cap)}"])
+        for k in drop:
+            cfg["test_class"]["init_args"].pop(k, None)
+        old_init = TS.TestVAESamplerBase.on_test_start
+
+        def patched(self, _cap=cap, _old=old_init):
+            _old(self)
+            self.max_iterations_per_call = _cap
+        TS.TestVAESamplerBase.on_test_start = patched
+        try:
+            tester, outs = driver.run(cfg)
+        finally:
+            TS.TestVAESamplerBase.on_test_start = old_init
+        files = {n: dict(np.load(os.path.join(tester.out_dir, n))) for n in sorted(os.listdir(tester.out_dir)) if n.endswith(".npz")}
+        res.append((files, outs))
+    (f1, o1), (f8, o8) = res
+    assert sorted(f1) == sorted(f8) and "imputations_0.npz" in f1 and len(o1) == len(o8) == batches
+    for n in f1:
+        for k in f1[n]:
+            if n == "metrics_summary.npz" and not any(m in k for m in ("rmse", "mae", "latent_wass")):
+                np.testing.assert_allclose(f1[n][k], f8[n][k], rtol=1e-6)
+            else:
+                assert np.array_equal(f1[n][k], f8[n][k], equal_nan=True), f"{n}[{k}] differs"
+    T = f1["imputations_0.npz"]["imputations"].shape[0] - 1
+    for a, b in zip(o1, o8):
+        for name in ("rmse", "mae", "latent_wass"):
+            va, vb = _host(a[f"imp_metric/{name}"]), _host(b[f"imp_metric/{name}"])
+            assert va.shape == (T, 40, va.shape[2]) and np.array_equal(va, vb), name
+        for key in a:
+            if not key.startswith("imp_metric/"):
+                np.testing.assert_allclose(a[key], b[key], rtol=1e-6, err_msg=key)
 
 
 def test_yaml_driver_selects_the_arithmetic_per_run(tmp_path):

@@ -124,6 +124,14 @@ class cs_lair_run_out(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("Z_store", "log_w_store", "ess_store", "tess_store", "perplexity_store")]
 
 
+class cs_run_observe(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("X_store", "X_true", "rmse_store", "mae_store", "q_true", "q_work", "wass_store")]
+
+
+class cs_acmwg_run_out(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("accepted_store", "log_accept_store", "slots_store", "Z_store")]
+
+
 class cs_acmwg_cfg(C.Structure):
     _fields_ = [("B", C.c_int32), ("K", C.c_int32), ("D", C.c_int32), ("Zd", C.c_int32),
                 ("latent_dist", C.c_int32), ("gen_dist", C.c_int32), ("hist_len", C.c_int32),
@@ -177,6 +185,10 @@ def lib():
     L.cs_lair_step.argtypes = [vp, vp, C.POINTER(cs_lair_cfg), C.POINTER(cs_lair_bufs), C.POINTER(cs_rng), vp]
     L.cs_lair_run.argtypes = [vp, vp, C.POINTER(cs_lair_cfg), C.POINTER(cs_lair_bufs), C.POINTER(cs_rng), i32,
                               C.POINTER(cs_lair_run_out), vp]
+    L.cs_lair_run_observed.argtypes = [vp, vp, C.POINTER(cs_lair_cfg), C.POINTER(cs_lair_bufs), C.POINTER(cs_rng), i32,
+                                       C.POINTER(cs_lair_run_out), C.POINTER(cs_run_observe), vp]
+    L.cs_acmwg_run.argtypes = [vp, vp, C.POINTER(cs_acmwg_cfg), C.POINTER(cs_acmwg_bufs), C.POINTER(cs_rng), i32,
+                               C.POINTER(cs_acmwg_run_out), C.POINTER(cs_run_observe), vp]
     L.cs_acmwg_init_state.argtypes = [vp, vp, C.POINTER(cs_acmwg_cfg), C.POINTER(cs_acmwg_bufs), C.POINTER(cs_rng), vp]
     L.cs_acmwg_step.argtypes = [vp, vp, C.POINTER(cs_acmwg_cfg), C.POINTER(cs_acmwg_bufs), C.POINTER(cs_rng), vp]
     L.cs_history_concat.argtypes = [vp, vp, i64, i32, i32, i32, C.POINTER(i32), C.POINTER(i32), vp,

@@ -476,6 +476,48 @@ extern "C" int cs_acmwg_step(const cs_mlp_t* enc, const cs_mlp_t* dec, const cs_
   return CS_OK;
 }
 
+// T steps in one call: the loop of the MWG samplers for callers that need nothing on the host between steps.  The
+// history scalars advance as the reference's queue does (utils.py:41-44).
+extern "C" int cs_acmwg_run(const cs_mlp_t* enc, const cs_mlp_t* dec, const cs_acmwg_cfg* c0, const cs_acmwg_bufs* b0,
+                            const cs_rng* rng, int32_t T, const cs_acmwg_run_out* out, const cs_run_observe* obs,
+                            void* stream) {
+  CS_REQUIRE(c0 && b0 && T >= 0, "bad argument");
+  if (int rc = check_acmwg(c0, b0)) return rc;
+  if (int rc = cs_observe_check(obs, c0->latent_dist)) return rc;
+  const int64_t chains = (int64_t)c0->B * c0->K;
+  const int64_t n_z = chains * c0->Zd, n_x = chains * c0->D;
+  const bool use_hist = !(c0->flags & CS_MWG_PROPOSE_FROM_CURRENT);
+  cs_acmwg_cfg c = *c0;
+  cs_rng r = rng ? *rng : cs_rng{0, 0, 0};
+  for (int32_t t = 0; t < T; ++t) {
+    cs_acmwg_bufs b = *b0;
+    if (b.r_hist) b.r_hist += t * chains;
+    if (b.eps_z) b.eps_z += t * n_z;
+    if (b.z_prior) b.z_prior += t * n_z;
+    if (b.u_prior) b.u_prior += t * chains;
+    if (b.u_accept) b.u_accept += t * chains;
+    if (b.eps_x) b.eps_x += t * n_x;
+    if (b.chi2_x) b.chi2_x += t * n_x;
+    if (out) {
+      if (out->accepted_store) b.accepted = out->accepted_store + t * chains;
+      if (out->log_accept_store) b.log_accept = out->log_accept_store + t * chains;
+      if (out->slots_store) b.slots = out->slots_store + t * chains;
+    }
+    cs_rng rt = r;
+    rt.iteration = r.iteration + (uint32_t)t;
+    if (int rc = cs_acmwg_step(enc, dec, &c, &b, &rt, stream)) return rc;
+    if (use_hist) {
+      c.hist_tail = (c.hist_tail + 1) % c.hist_len;
+      if (c.hist_tail == c.hist_len - 1) c.hist_full = 1;
+    }
+    if (out && out->Z_store && chains)
+      CS_HIP(hipMemcpyAsync(out->Z_store + t * n_z, b.Z_old, (size_t)n_z * sizeof(float), hipMemcpyDeviceToDevice,
+                            (hipStream_t)stream));
+    if (int rc = cs_observe_iteration(enc, obs, t, b.X, b.M, c.B, c.K, c.D, c.Zd, c.latent_dist, stream)) return rc;
+  }
+  return CS_OK;
+}
+
 // LAIR's historical proposals: Xc[b] = (X[b, 0..K), ring[slots[h], b, chain] for h < H).
 struct CsHistConcatArgs {
   const float* X; const float* ring; const uint8_t* ring8; float* Xc; const int64_t* chain_of_example; CsPhilox rng;

@@ -837,8 +837,18 @@ extern "C" int cs_sample_impute2(const float* gen, int32_t gen_dist, const float
 // ----------------------------------------------------------------------------------------
 extern "C" int cs_lair_run(const cs_mlp_t* enc, const cs_mlp_t* dec, const cs_lair_cfg* c, const cs_lair_bufs* b0,
                            const cs_rng* rng, int32_t T, const cs_lair_run_out* out, void* stream) {
+  return cs_lair_run_observed(enc, dec, c, b0, rng, T, out, nullptr, stream);
+}
+
+extern "C" int cs_lair_run_observed(const cs_mlp_t* enc, const cs_mlp_t* dec, const cs_lair_cfg* c, const cs_lair_bufs* b0,
+                                    const cs_rng* rng, int32_t T, const cs_lair_run_out* out, const cs_run_observe* obs,
+                                    void* stream) {
   CS_REQUIRE(c && b0 && T >= 0, "bad argument");
   if (int rc = check_cfg(c, b0)) return rc;
+  if (obs) {
+    CS_REQUIRE(!b0->X_out && (c->K_impute == 0 || c->K_impute == c->K), "an observed run imputes all chains in place");
+    if (int rc = cs_observe_check(obs, c->latent_dist)) return rc;
+  }
   const int64_t B = c->B, Kp = c->K + c->R, I = c->I, Zd = c->Zd;
   const int64_t Kimp = c->K_impute > 0 ? c->K_impute : c->K;
   const int64_t Kg = c->glr_pad_to > 0 && c->scheme == CS_RS_GLR ? c->glr_pad_to : Kp;
@@ -869,6 +879,7 @@ extern "C" int cs_lair_run(const cs_mlp_t* enc, const cs_mlp_t* dec, const cs_la
     cs_rng rt = r;
     rt.iteration = r.iteration + (uint32_t)t;
     if (int rc = cs_lair_step(enc, dec, c, &b, &rt, stream)) return rc;
+    if (int rc = cs_observe_iteration(enc, obs, t, b.X, b.M, B, c->K, c->D, c->Zd, c->latent_dist, stream)) return rc;
   }
   return CS_OK;
 }

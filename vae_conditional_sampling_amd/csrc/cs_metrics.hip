@@ -5,6 +5,9 @@
 // imputation_mae_metric (:133-143) and the closed-form part of imputation_latent_wass (:200-213),
 // as called once per iteration from test_step (irwg/sampling/test_step_vae_sampling.py:431-445).
 #include "cs_common.h"
+#include "cs_mlp.h"
+
+#include <cstring>
 
 namespace {
 
@@ -141,5 +144,45 @@ extern "C" int cs_latent_wasserstein(const float* q_imp, const float* q_true, in
   hipLaunchKernelGGL(cs_latent_wass_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream, q_imp,
                      q_true, rows, K, Zd, out);
   CS_HIP(hipGetLastError());
+  return CS_OK;
+}
+
+// ----------------------------------------------------------------------------------------
+// The per-iteration work of the harness inside a run of several iterations (cs_run_observe): keep the
+// imputations, compute the diagnostics (test_step_vae_sampling.py:386-391, 431-445).
+// ----------------------------------------------------------------------------------------
+int cs_observe_check(const cs_run_observe* o, int32_t latent_dist) {
+  if (!o) return CS_OK;
+  CS_REQUIRE(!(o->rmse_store || o->mae_store) || o->X_true, "rmse / mae stores need X_true");
+  if (o->wass_store) {
+    CS_REQUIRE(o->q_true && o->q_work, "the latent distance needs q_true and q_work");
+    if (latent_dist == CS_DIST_BETA) return cs_fail(CS_EUNSUPPORTED, "latent Wasserstein distance: Gaussian posteriors only");
+  }
+  return CS_OK;
+}
+
+int cs_observe_iteration(const cs_mlp_t* enc, const cs_run_observe* o, int32_t t, const float* X, const uint8_t* M,
+                         int64_t B, int32_t K, int32_t D, int32_t Zd, int32_t latent_dist, void* stream) {
+  if (!o || B == 0) return CS_OK;
+  const int64_t chains = B * K;
+  if (o->X_store)
+    CS_HIP(hipMemcpyAsync(o->X_store + (int64_t)t * chains * D, X, (size_t)chains * D * sizeof(float),
+                          hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  if (o->rmse_store || o->mae_store)
+    if (int rc = cs_imputation_errors(X, o->X_true, M, B, K, D, o->rmse_store ? o->rmse_store + (int64_t)t * chains : nullptr,
+                                      o->mae_store ? o->mae_store + (int64_t)t * chains : nullptr, stream))
+      return rc;
+  if (o->wass_store) {
+    // VAE.compute_var_distr of the imputed data (imputation_metrics.py:203-207): the encoder on X as it is
+    cs_lair_cfg c;
+    std::memset(&c, 0, sizeof(c));
+    c.B = (int32_t)B; c.K = K; c.R = 0; c.I = 1; c.D = D; c.Zd = Zd; c.latent_dist = latent_dist;
+    c.gen_dist = CS_DIST_NORMAL; c.weight_alpha = 1.0f; c.prior = CS_PRIOR_STD_NORMAL;
+    cs_lair_bufs b;
+    std::memset(&b, 0, sizeof(b));
+    b.X = const_cast<float*>(X); b.q = o->q_work;
+    if (int rc = cs_lair_encode(enc, &c, &b, stream)) return rc;
+    if (int rc = cs_latent_wasserstein(o->q_work, o->q_true, B, K, Zd, o->wass_store + (int64_t)t * chains, stream)) return rc;
+  }
   return CS_OK;
 }

@@ -79,5 +79,11 @@ struct CsMlpArgs {
 };
 
 int cs_mlp_launch(const CsMlpArgs& a, hipStream_t stream);
+
+// The harness's per-iteration work of a run (cs_run_observe), after iteration t left X[B,K,D]: defined with the
+// diagnostics kernels.
+int cs_observe_check(const cs_run_observe* o, int32_t latent_dist);
+int cs_observe_iteration(const cs_mlp_t* enc, const cs_run_observe* o, int32_t t, const float* X, const uint8_t* M,
+                         int64_t B, int32_t K, int32_t D, int32_t Zd, int32_t latent_dist, void* stream);
 // CS_ARITH_* in force for fused-MLP launches (cs_set_mlp_arith, or CSVAE_MLP_ARITH at first use)
 int cs_mlp_arith();

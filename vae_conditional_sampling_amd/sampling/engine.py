@@ -123,20 +123,62 @@ def lair_step(model, ws, X, M8, cfg, *, rng=None, draws=None, return_resampled_l
     return ws
 
 
+class RunObserver:
+    """What the harness does with the chains after every iteration, handed to a run of several iterations
+    (cs_run_observe): ``X_store`` [T,B,K,D] keeps the imputations, ``rmse`` / ``mae`` / ``wass`` [T,B,K] receive the
+    diagnostics.  ``X_true`` [B,D] is needed by rmse / mae, ``q_true`` [B,1,2,Zd] (the posterior of the true data) by
+    wass.  ``window(t, n)`` is the observer of iterations t .. t+n-1 of the same stores."""
+
+    def __init__(self, *, X_store=None, X_true=None, rmse=None, mae=None, q_true=None, wass=None):
+        self.X_store, self.X_true, self.rmse, self.mae, self.q_true, self.wass = X_store, X_true, rmse, mae, q_true, wass
+        self._q_work = None
+
+    def window(self, t, n):
+        cut = lambda a: None if a is None else a[t:t + n]
+        o = RunObserver(X_store=cut(self.X_store), X_true=self.X_true, rmse=cut(self.rmse), mae=cut(self.mae),
+                        q_true=self.q_true, wass=cut(self.wass))
+        o._q_work = self._q_work
+        return o
+
+    def struct(self, B, K, Zd, device):
+        if self.wass is not None and self._q_work is None:
+            self._q_work = torch.empty(B, K, 2, Zd, device=device, dtype=torch.float32)
+        return _lib.cs_run_observe(_lib.ptr(self.X_store), _lib.ptr(self.X_true), _lib.ptr(self.rmse), _lib.ptr(self.mae),
+                                   _lib.ptr(self.q_true), _lib.ptr(self._q_work) if self.wass is not None else None,
+                                   _lib.ptr(self.wass))
+
+
 def lair_run(model, ws, X, M8, cfg, T, *, rng=None, draws=None, Z_store=None, log_w_store=None, stats_store=None,
-             clip_min=None, clip_max=None):
-    """``T`` LAIR iterations in place on ``X`` [B,K,D] in one library call (cs_lair_run): iteration t is
+             clip_min=None, clip_max=None, observe=None):
+    """``T`` LAIR iterations in place on ``X`` [B,K,D] in one library call (cs_lair_run_observed): iteration t is
     ``lair_step`` with ``rng.iteration + t``.  ``draws``: the injected draws of all iterations stacked along a
     leading T axis.  ``Z_store`` [T,I,B,K',Zd] / ``log_w_store`` [T,I,B,K'] receive every iteration's proposals and
-    log-weights, ``stats_store`` [3,T,B] its ESS, transformed ESS and perplexity."""
+    log-weights, ``stats_store`` [3,T,B] its ESS, transformed ESS and perplexity; ``observe`` (RunObserver) keeps
+    the imputations and computes the diagnostics of every iteration."""
     bufs, keep = _lair_bufs(ws, X, M8, cfg, draws, False, clip_min, clip_max, None)
     rng = rng if rng is not None else _lib.make_rng(0)
     out = _lib.cs_lair_run_out(_lib.ptr(Z_store), _lib.ptr(log_w_store),
                                *(_lib.ptr(stats_store[i]) if stats_store is not None else None for i in range(3)))
+    obs = observe.struct(ws.B, ws.K, ws.Zd, X.device) if observe is not None else None
     enc, dec = model.var_latent_network.packed(), model.generator_network.packed()
-    _lib.check(_lib.lib().cs_lair_run(enc.handle, dec.handle, C.byref(cfg), C.byref(bufs), C.byref(rng), int(T),
-                                      C.byref(out), _lib.current_stream()))
+    _lib.check(_lib.lib().cs_lair_run_observed(enc.handle, dec.handle, C.byref(cfg), C.byref(bufs), C.byref(rng), int(T),
+                                               C.byref(out), C.byref(obs) if obs is not None else None,
+                                               _lib.current_stream()))
     return ws
+
+
+def acmwg_run(model, cfg, bufs, T, *, rng=None, accepted_store=None, log_accept_store=None, slots_store=None,
+              Z_store=None, observe=None, device=None):
+    """``T`` Metropolis-within-Gibbs steps in one library call (cs_acmwg_run): step t is cs_acmwg_step with
+    ``rng.iteration + t`` and the history tail advanced t slots.  The stores [T,B,K] (``Z_store`` [T,B,K,Zd]) receive
+    every step's outputs; the caller advances its history scalars ``T`` times afterwards."""
+    rng = rng if rng is not None else _lib.make_rng(0)
+    out = _lib.cs_acmwg_run_out(_lib.ptr(accepted_store), _lib.ptr(log_accept_store), _lib.ptr(slots_store), _lib.ptr(Z_store))
+    device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+    obs = observe.struct(cfg.B, cfg.K, cfg.Zd, device) if observe is not None else None
+    enc, dec = model.var_latent_network.packed(), model.generator_network.packed()
+    _lib.check(_lib.lib().cs_acmwg_run(enc.handle, dec.handle, C.byref(cfg), C.byref(bufs), C.byref(rng), int(T),
+                                       C.byref(out), C.byref(obs) if obs is not None else None, _lib.current_stream()))
 
 
 def decode_params(model, Z):

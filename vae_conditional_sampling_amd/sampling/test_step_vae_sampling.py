@@ -155,9 +155,10 @@ class TestVAESamplerBase(HyperparametersMixin):
         self.collector = None
         self.skip_unimplemented_diagnostics = False
         self._iteration = 0
-        # engine-side: a predicate t -> bool telling the sampler at which iterations the consumer looks at the chain
-        # state (None: at every one).  A sampler may run the iterations in between in one library call.
-        self._state_needed = None
+        # engine-side: while test_step iterates over the sampler, what it does with every iteration's state
+        # (_HarnessPlan; None outside test_step).  A sampler may take that work over and run up to
+        # max_iterations_per_call iterations in one library call.
+        self._harness = None
         self.max_iterations_per_call = 64
 
     # ---- wiring -------------------------------------------------------------------------
@@ -345,20 +346,22 @@ class TestVAESamplerBase(HyperparametersMixin):
         def stored(t_):
             return ((hp.store_last_n_iterations == -1 or (self.max_iterations - hp.store_last_n_iterations) <= t_)
                     and t_ % hp.store_every_n_iterations == 0)
-        # the chain state is read at iteration t when a diagnostic is computed from it, when it is stored, and at
-        # the end; a sampler may run the stretches in between without coming back to the host
-        last = self.max_iterations - 1
-        self._state_needed = (lambda t_: True) if point else (lambda t_: stored(t_) or t_ >= last)
+        # The chain state is read after iteration t when a diagnostic is computed from it and when it is stored.  A
+        # sampler may take both over (self._harness.observer) and run many iterations in one library call; it then
+        # marks what it yields as '_observed' (diagnostics of this iteration are in the buffers) and its 'X' as
+        # '_X_private' (a tensor of its own that nothing overwrites: kept without a copy).
+        self._harness = _HarnessPlan(point, truth, q_true, stored)
         for t, outputs in enumerate(self.sampler(X, M)):
             X = outputs['X']
-            if 'rmse' in point or 'mae' in point:  # one launch for both
-                imputation_metrics.imputation_errors(X, truth, rmse=point['rmse'][t] if 'rmse' in point else None,
-                                                     mae=point['mae'][t] if 'mae' in point else None)
-            if 'latent_wass' in point:
-                imputation_metrics.imputation_latent_wass(X, X_true1, self.model, q_true=q_true, out=point['latent_wass'][t])
-            if ((hp.store_last_n_iterations == -1 or (self.max_iterations - hp.store_last_n_iterations) <= t)
-                    and t % hp.store_every_n_iterations == 0):
-                imputations.append(X.clone())
+            if not outputs.get('_observed'):
+                if 'rmse' in point or 'mae' in point:  # one launch for both
+                    imputation_metrics.imputation_errors(X, truth, rmse=point['rmse'][t] if 'rmse' in point else None,
+                                                         mae=point['mae'][t] if 'mae' in point else None)
+                if 'latent_wass' in point:
+                    imputation_metrics.imputation_latent_wass(X, X_true1, self.model, q_true=q_true,
+                                                              out=point['latent_wass'][t])
+            if stored(t):
+                imputations.append(X if outputs.get('_X_private') else X.clone())
                 if hp.store_latents:
                     latents.append(outputs['Z'].clone())
             for key, val in outputs.items():
@@ -370,7 +373,7 @@ class TestVAESamplerBase(HyperparametersMixin):
             imputations.append(X.clone())
             if hp.store_latents:
                 latents.append(outputs['Z'].clone())
-        self._state_needed = None
+        self._harness = None
         # one device->host transfer for the whole sequence
         imps = torch.stack(imputations).cpu().numpy()
         if bool_data:
@@ -388,6 +391,25 @@ class TestVAESamplerBase(HyperparametersMixin):
             self.metrics[key].append(value)
         self.metrics['num_X'].append(X_true.shape[0])
         return out
+
+
+class _HarnessPlan:
+    """What test_step does with the state after every iteration: the point-wise diagnostic buffers [T,B,K] it fills
+    (``point``: 'rmse' / 'mae' / 'latent_wass'), what they are computed against, and which iterations it keeps.
+    ``observer(t, n, ...)`` hands the same work for the iterations t .. t+n-1 to a run of n iterations in one
+    library call (engine.RunObserver)."""
+
+    def __init__(self, point, truth, q_true, stored):
+        self.point, self.truth, self.q_true, self.stored = point, truth, q_true, stored
+
+    def observer(self, t, n, shape, device):
+        B, K, D = shape
+        cut = lambda name: self.point[name][t:t + n] if name in self.point else None
+        keep = any(self.stored(t + i) for i in range(n))
+        return engine.RunObserver(
+            X_store=torch.empty(n, B, K, D, device=device, dtype=torch.float32) if keep else None,
+            X_true=self.truth.Xt if self.truth is not None else None, rmse=cut('rmse'), mae=cut('mae'),
+            q_true=self.q_true, wass=cut('latent_wass'))
 
 
 def _means_of_three(a, b, c):
@@ -566,20 +588,16 @@ class TestVAELatentAdaptiveImportanceResampling(TestVAESamplerBase):
 
         all_norm_log_weights = []
         T = hp.num_iterations
-        # Stretches of iterations whose state nobody reads run in one library call (cs_lair_run): same kernels,
-        # same counter-RNG iteration numbers, so the chain is bit for bit the one of single steps.
-        can_run = (self._state_needed is not None and self.draw_source is None and history is None
+        # Under the harness of test_step the iterations run max_iterations_per_call at a time in one library call
+        # (cs_lair_run_observed), which also does the harness's work on every iteration's state: same kernels, same
+        # counter-RNG iteration numbers, so the chain is bit for bit the one of single steps.
+        can_run = (self._harness is not None and self.draw_source is None and history is None
                    and not hp.store_latents and hp.weight_transform is None and not hp.store_norm_log_weights
                    and hp.prior_replenish_iteration_frequency == 1 and self.max_iterations_per_call > 1)
         t = 0
         while t < T:
-            n = 1
-            while (can_run and t + n < T and n < self.max_iterations_per_call
-                   and not self._state_needed(hp.num_pseudo_warmup_iterations + t + n - 1)):
-                n += 1
+            n = min(T - t, self.max_iterations_per_call) if can_run else 1
             if n == 1:
-                # the consumer reads this iteration's state (or nothing can be batched): one single step, after
-                # which the next stretch may be batched again
                 yield from self._single_step(t, T, X, M, history, clip_min, clip_max, all_norm_log_weights)
                 t += 1
                 continue
@@ -592,15 +610,18 @@ class TestVAELatentAdaptiveImportanceResampling(TestVAESamplerBase):
                 self._proposals = (torch.empty((T,) + tuple(ws.Z.shape), device=X.device),
                                    torch.empty((T,) + tuple(ws.log_w.shape), device=X.device))
             stats = torch.empty(3, n, B, device=X.device)
+            obs = self._harness.observer(hp.num_pseudo_warmup_iterations + t, n, (B, K, D), X.device)
             engine.lair_run(self.model, ws, X, engine.mask_u8(M), cfg, n, rng=self._rng(),
                             Z_store=self._proposals[0][t:t + n] if hp.resample_final_imps else None,
                             log_w_store=self._proposals[1][t:t + n] if hp.resample_final_imps else None,
-                            stats_store=stats, clip_min=clip_min, clip_max=clip_max)
+                            stats_store=stats, clip_min=clip_min, clip_max=clip_max, observe=obs)
             self._iteration += n
-            means = stats.mean(dim=2)   # [3, n]
+            means = stats.mean(dim=2).tolist()   # [3][n]: one read for the stretch
             for i in range(n):
-                yield {'X': X, 'Z': None, 'is_ess': means[0, i], 'is_ess_not_reduced': stats[0, i],
-                       'transformed_ess': means[1, i], 'perplexity': means[2, i],
+                kept = obs.X_store is not None
+                yield {'X': obs.X_store[i] if kept else X, '_X_private': kept, '_observed': True, 'Z': None,
+                       'is_ess': means[0][i], 'is_ess_not_reduced': stats[0, i],
+                       'transformed_ess': means[1][i], 'perplexity': means[2][i],
                        'total_num_props': hp.num_imp_samples * (K + R), 'acceptance_x': 1.0}
             t += n
 
@@ -962,6 +983,48 @@ class _MetropolisWithinGibbsCommon(TestVAESamplerBase):
                              stream_id=_lib.STREAM_X)
         return X, ws.Z[0]
 
+    def _warmup_yields(self):
+        """States the warm-up yields before the first MWG step (the harness counts them as iterations)."""
+        hp = self.hparams
+        if hp.warmup_method == 'pseudo_gibbs':
+            return hp.num_pseudo_warmup_iterations
+        if hp.warmup_method == 'irwg':
+            return hp.num_pseudo_warmup_iterations * hp.num_k_per_cluster
+        return 0
+
+    def _steps_per_call(self, remaining):
+        """How many of the remaining MWG steps the next library call runs: under the harness of test_step, with
+        counter-RNG draws, max_iterations_per_call at a time (cs_acmwg_run, which also does the harness's work on
+        every step's state); one otherwise."""
+        if (self._harness is None or self.draw_source is not None or self.hparams.store_latents
+                or self.max_iterations_per_call <= 1):
+            return 1
+        return min(remaining, self.max_iterations_per_call)
+
+    def _run_steps(self, n, t, X, M8, cfg, bufs, st, history):
+        """MWG steps t .. t+n-1 in one library call; yields what the single steps yield.  Same kernels, same
+        counter-RNG iteration numbers and history slots, so the chains are bit for bit those of single steps."""
+        B, K, D = X.shape
+        dev = X.device
+        acc = torch.empty(n, B, K, device=dev, dtype=torch.uint8)
+        log_acc = torch.empty(n, B, K, device=dev, dtype=torch.float32)
+        slots = torch.empty(n, B, K, device=dev, dtype=torch.int64) if history is not None else None
+        obs = self._harness.observer(self._warmup_yields() + t, n, (B, K, D), dev)
+        engine.acmwg_run(self.model, cfg, bufs, n, rng=self._rng(), accepted_store=acc, log_accept_store=log_acc,
+                         slots_store=slots, observe=obs, device=dev)
+        self._iteration += n
+        if history is not None:
+            for _ in range(n):
+                history.advance()
+        means = acc.float().mean(dim=(1, 2)).tolist()   # one read for the stretch
+        kept = obs.X_store is not None
+        for i in range(n):
+            out = {'X': obs.X_store[i] if kept else X, '_X_private': kept, '_observed': True, 'Z': st["Z_old"],
+                   'acceptance': means[i], '_accepted': acc[i], '_log_accept': log_acc[i]}
+            if slots is not None:
+                out['_slots'] = slots[i]
+            yield out
+
     def _chain_buffers(self, B, K, D, Zd, P, dev):
         f = dict(device=dev, dtype=torch.float32)
         st = dict(Z_old=torch.empty(B, K, Zd, **f), gen_old=torch.empty(B, K, P, **f),
@@ -1042,7 +1105,13 @@ class TestVAEMetropolisWithinGibbs(_MetropolisWithinGibbsCommon):
             _lib.check(L.cs_acmwg_init_state(h_enc, h_dec, C.byref(cfg), C.byref(bufs), C.byref(rng), stream))
             self._next_iteration()
 
-        for t in range(hp.num_mwg_iterations):
+        t, T = 0, hp.num_mwg_iterations
+        while t < T:
+            n = self._steps_per_call(T - t)
+            if n > 1:
+                yield from self._run_steps(n, t, X, M8, cfg, _lib.make_acmwg_bufs(X=X, M=M8, **st, **wk), st, None)
+                t += n
+                continue
             d = {}
             if src is not None:
                 d["eps_z"] = src.normal(B, K, Zd).to(dev).contiguous()
@@ -1054,6 +1123,7 @@ class TestVAEMetropolisWithinGibbs(_MetropolisWithinGibbsCommon):
             self._next_iteration()
             yield {'X': X, 'Z': st["Z_old"], 'acceptance': wk["accepted"].float().mean(),
                    '_accepted': wk["accepted"], '_log_accept': wk["log_accept"]}
+            t += 1
 
 
 class TestVAEAdaptiveCollapsedMetropolisWithinGibbs(_MetropolisWithinGibbsCommon):
@@ -1160,7 +1230,16 @@ class TestVAEAdaptiveCollapsedMetropolisWithinGibbs(_MetropolisWithinGibbsCommon
             self._next_iteration()
         history.update_available_timesteps(None)
 
-        for t in range(hp.num_mwg_iterations):
+        t, T = 0, hp.num_mwg_iterations
+        while t < T:
+            n = self._steps_per_call(T - t)
+            if n > 1:
+                bufs = _lib.make_acmwg_bufs(X=X, M=M8, ring=history.history_queue, avail=history.available_timesteps,
+                                            **st, **wk)
+                yield from self._run_steps(n, t, X, M8, cfg_now(), bufs, st, history)
+                t += n
+                continue
+            t += 1
             d = {}
             if src is not None:
                 bounds = torch.clamp(history.available_timesteps, min=1).cpu()

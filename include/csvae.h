@@ -410,6 +410,15 @@ int cs_imputation_errors(const float* X, const float* X_true, const uint8_t* M, 
 int cs_latent_wasserstein(const float* q_imp, const float* q_true, int64_t B, int32_t K, int32_t Zd, float* out,
                           void* stream);
 
+/* HOST function (no device work, callable from any thread): one piece of a raw deflate stream (RFC 1951) for
+ * src[0..n), for the `.npz` artefacts the samplers write with np.savez_compressed (test_step_vae_sampling.py:785-791,
+ * 2039-2045).  Matches are looked for at distance `stride` only (the row length in bytes of a [.., K, D] array,
+ * 1..32768: the observed entries of a row repeat the row before it), symbols are coded with the fixed Huffman code,
+ * and the piece is closed by an empty stored block, so pieces concatenate into one valid stream that any inflate
+ * reads.  `lookback`: how many bytes before src belong to the same stream and are readable at src - lookback.
+ * Returns the number of bytes written to dst, or -1 (dst_cap too small: n + n/8 + 64 always suffices). */
+int64_t cs_deflate_rows(const uint8_t* src, int64_t n, int32_t stride, int64_t lookback, uint8_t* dst, int64_t dst_cap);
+
 /* gen[rows,2,D] (mean, scale), [rows,D] (Bernoulli logits) or [rows,3,D] (Student-t: loc, scale, df) = generator parameterisation of
  * generator_network(Z[rows,Zd]) (vae.py:171-172,203-256). */
 int cs_decode_params(const cs_mlp_t* dec, const float* Z, int64_t rows, int32_t gen_dist, float* gen, void* stream);

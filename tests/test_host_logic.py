@@ -353,6 +353,50 @@ def test_parallel_npz_writer_matches_numpy(tmp_path):
     assert size("a.npz") < 1.1 * size("b.npz")     # independent pieces cost little compression
 
 
+def test_row_encoder_writes_what_numpy_reads(tmp_path):
+    """Float arrays of short rows (the kept imputations [T,B,K,D]) are deflated by the library's own encoder
+    (cs_deflate_rows, host code): np.load must return them bit for bit, including NaNs, across pieces, write slices
+    and 256 KiB block boundaries, and the files must not be larger than zlib's by more than a few percent."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    from vae_conditional_sampling_amd.utils import artifacts
+    rs = np.random.RandomState(1)
+    T, B, K, D = 40, 300, 4, 43
+    Xt = rs.randn(1, B, 1, D).astype(np.float32)
+    M = rs.rand(1, B, 1, D) < 0.5
+    imps = np.where(M, Xt, rs.randn(T, B, K, D).astype(np.float32)).astype(np.float32)      # 8.3 MB
+    imps[3, 7, 2, 5] = np.nan
+    wide = rs.randn(40, 8192).astype(np.float32)                   # rows of exactly 32768 bytes: the largest distance
+    dbl = np.repeat(rs.randn(50, 1, 30), 90, axis=1)               # float64, every row repeats: long matches
+    const = np.zeros((600, 500), np.float32)                       # one symbol only
+    arrays = dict(imputations=imps, wide=wide, dbl=dbl, const=const, masks=M[0], latents=[])
+    assert artifacts.row_stride_of(imps) == 172 and artifacts.row_stride_of(wide) == 32768
+    assert artifacts.row_stride_of(rs.randn(4, 10000)) is None and artifacts.row_stride_of(M[0]) is None
+    assert artifacts.row_stride_of(imps[:2]) is None               # small arrays stay with zlib
+    old_piece, old_slice = artifacts._PIECE, artifacts._SLICE
+    for piece, slc, name in ((old_piece, old_slice, "a.npz"), (300000, 1000000, "b.npz"), (4097, 4097 * 5, "c.npz")):
+        artifacts._PIECE, artifacts._SLICE = piece, slc
+        try:
+            with ThreadPoolExecutor(4) as pool:
+                artifacts.savez_compressed_parallel(tmp_path / name, pool, **arrays)
+        finally:
+            artifacts._PIECE, artifacts._SLICE = old_piece, old_slice
+        got = np.load(tmp_path / name)
+        assert sorted(got.files) == sorted(arrays)
+        for k, v in arrays.items():
+            v = np.asarray(v)
+            assert got[k].dtype == v.dtype and got[k].shape == v.shape
+            assert got[k].tobytes() == v.tobytes(), (name, k)
+    np.savez_compressed(tmp_path / "ref.npz", **arrays)
+    size = lambda n: (tmp_path / n).stat().st_size
+    assert size("a.npz") < 1.05 * size("ref.npz")
+    # a piece on its own is a valid raw deflate stream once closed
+    import zlib
+    raw = imps.tobytes()[:100000]
+    piece = artifacts.deflate_rows(memoryview(raw), 172, 0) + zlib.compressobj(6, zlib.DEFLATED, -15).flush(zlib.Z_FINISH)
+    assert zlib.decompress(piece, -15) == raw
+
+
 def test_sharded_artifact_merge_passes_switched_off_entries_through(tmp_path):
     """An option that is off is stored as an empty list in the artefact files (``latents`` without
     ``store_latents``), also where the example axis of that key is 0 (final-resampling files): merging shards,

@@ -210,6 +210,8 @@ def lib():
     L.cs_mlp_set_arith.argtypes = [vp, i32]
     L.cs_mlp_get_arith.argtypes = [vp]
     L.cs_net_reserve.argtypes = [vp, i64]
+    L.cs_deflate_rows.restype = i64
+    L.cs_deflate_rows.argtypes = [vp, i64, i32, i64, vp, i64]
     L.cs_imputation_errors.argtypes = [vp, vp, vp, i64, i32, i32, vp, vp, vp]
     L.cs_latent_wasserstein.argtypes = [vp, vp, i64, i32, i32, vp, vp]
     L.cs_sample_impute.argtypes = [vp, i32, vp, C.POINTER(cs_rng), u32, vp, vp, i64, i32, i32, vp, vp, i32, vp]

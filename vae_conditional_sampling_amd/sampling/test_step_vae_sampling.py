@@ -375,10 +375,10 @@ class TestVAESamplerBase(HyperparametersMixin):
                 latents.append(outputs['Z'].clone())
         self._harness = None
         # one device->host transfer for the whole sequence
-        imps = torch.stack(imputations).cpu().numpy()
+        imps = _to_host(torch.stack(imputations))
         if bool_data:
             imps = imps.astype(bool)
-        lat = torch.stack(latents).cpu().numpy() if latents else []
+        lat = _to_host(torch.stack(latents)) if latents else []
         self.last_imputations = imps
         if not hp.dont_store_imputations and self._stores_artifacts() and self._harness_writes_imputations:
             self._save_npz(f'imputations_{batch_idx}.npz',
@@ -391,6 +391,17 @@ class TestVAESamplerBase(HyperparametersMixin):
             self.metrics[key].append(value)
         self.metrics['num_X'].append(X_true.shape[0])
         return out
+
+
+def _to_host(t):
+    """Device tensor -> numpy array.  Large ones go through page-locked memory (a batch's kept imputations are
+    about a gigabyte, which the pageable path of ``.cpu()`` moves at a few GB/s); the framework's host allocator
+    keeps such blocks for the next batch once the artefact writer has let go of the array."""
+    if not t.is_cuda or t.numel() * t.element_size() < (8 << 20):
+        return t.cpu().numpy()
+    h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+    h.copy_(t)
+    return h.numpy()
 
 
 class _HarnessPlan:

@@ -13,7 +13,13 @@ for a minute: ``savez_compressed_parallel`` writes the same zip container (defla
 ``np.load``) with every member's deflate stream produced in independent pieces on a pool of threads, the way
 parallel gzip implementations do (each piece a raw deflate run closed by a full flush, an empty final block at
 the end: the concatenation is one valid stream).
+
+Large float arrays whose rows are short (the kept imputations [T,B,K,D]) go through the library's own deflate
+encoder instead of zlib (``cs_deflate_rows``: matches one row back only, a Huffman code per block): the same
+container and the same file sizes to within a percent, at several times zlib's speed per thread, which is what the
+end-to-end time of the published configurations was bound by.
 """
+import ctypes
 import os
 import threading
 import zipfile
@@ -22,8 +28,31 @@ from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 
+from .. import _lib
+
 _PIECE = 4 << 20          # bytes compressed per task
 _SLICE = 64 * _PIECE      # bytes handed to one write() call
+_ROW_ENCODER_MIN_BYTES = 1 << 20
+
+
+def deflate_rows(data, stride, lookback):
+    """One piece of a raw deflate stream for the bytes of ``data`` (a contiguous buffer), matches at distance
+    ``stride`` only (cs_deflate_rows); ``lookback`` bytes before it in memory belong to the same stream."""
+    src = np.frombuffer(data, dtype=np.uint8)
+    n = src.size
+    dst = np.empty(n + n // 8 + 64, dtype=np.uint8)
+    r = _lib.lib().cs_deflate_rows(src.ctypes.data, n, int(stride), int(lookback), dst.ctypes.data, dst.size)
+    if r < 0:
+        raise _lib.CsError(f"cs_deflate_rows failed: {_lib.lib().cs_last_error().decode()}")
+    return dst[:r].tobytes()
+
+
+def row_stride_of(arr):
+    """Row length in bytes when ``arr`` is an array the row encoder is meant for, else None."""
+    if arr.dtype.kind != "f" or arr.ndim < 2 or arr.nbytes < _ROW_ENCODER_MIN_BYTES:
+        return None
+    stride = arr.shape[-1] * arr.itemsize
+    return stride if 1 <= stride <= 32768 else None
 
 
 class _PieceDeflate:
@@ -45,6 +74,22 @@ class _PieceDeflate:
         return zlib.compressobj(self._level, zlib.DEFLATED, -15).flush(zlib.Z_FINISH)
 
 
+class _RowDeflate(_PieceDeflate):
+    """The same for an array of short rows: the pieces go through cs_deflate_rows.  ``compress`` is called with
+    consecutive slices of one contiguous buffer, so a piece may match into the bytes before it."""
+
+    def __init__(self, pool, level, stride):
+        super().__init__(pool, level)
+        self._stride, self._done = stride, 0
+
+    def compress(self, data):
+        mv = memoryview(data)
+        base = self._done
+        self._done += len(mv)
+        return b"".join(self._pool.map(lambda i: deflate_rows(mv[i:i + _PIECE], self._stride, base + i),
+                                       range(0, len(mv), _PIECE)))
+
+
 def savez_compressed_parallel(path, pool, level=6, **arrays):
     """``np.savez_compressed(path, **arrays)`` with the compression of every member spread over ``pool``."""
     path = os.fspath(path)
@@ -57,9 +102,12 @@ def savez_compressed_parallel(path, pool, level=6, **arrays):
                 if arr.dtype.hasobject or getattr(f, "_compressor", None) is None:
                     np.lib.format.write_array(f, arr, allow_pickle=True)     # numpy's own path
                     continue
-                f._compressor = _PieceDeflate(pool, level)
                 arr = arr if arr.flags.c_contiguous else np.ascontiguousarray(arr)   # (keeps 0-d arrays 0-d)
+                f._compressor = _PieceDeflate(pool, level)
                 np.lib.format.write_array_header_1_0(f, np.lib.format.header_data_from_array_1_0(arr))
+                stride = row_stride_of(arr)
+                if stride:   # from here on the stream is the array's memory: a piece may match into the bytes before it
+                    f._compressor = _RowDeflate(pool, level, stride)
                 raw = memoryview(arr.reshape(-1)).cast("B") if arr.size else memoryview(b"")
                 for i in range(0, len(raw), _SLICE):
                     f.write(raw[i:i + _SLICE])

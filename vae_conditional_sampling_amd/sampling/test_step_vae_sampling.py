@@ -706,11 +706,11 @@ class TestVAELatentAdaptiveImportanceResampling(TestVAESamplerBase):
         imps, Z, _ = self.final_resampling(X_true, M1)
         # float32 also for binary data: the reference decides its bool cast from the stored latents
         # (test_step_vae_sampling.py:1988-1989, never 0/1), so this file always holds float32
-        imps = imps.cpu().numpy()
+        imps = _to_host(imps)
         self.last_final_imputations = imps
         if self._stores_artifacts():
             self._save_npz(f'irwg_imputations_after_final_resampling_{batch_idx}.npz',
-                           imputations=imps, latents=Z.cpu().numpy() if self.hparams.store_latents else [],
+                           imputations=imps, latents=_to_host(Z) if self.hparams.store_latents else [],
                            true_X=X_true.unsqueeze(1).cpu().numpy(), masks=M1.cpu().numpy(),
                            data_idx=np.asarray(I.cpu() if torch.is_tensor(I) else I))
 
@@ -805,7 +805,7 @@ class TestVAEImportanceResampling(TestVAESamplerBase):
         I = batch[-1]
         M1 = M.to(self.device).bool().unsqueeze(1)
         imps, _, _ = self.final_resampling(X_true, M1)
-        imps = imps.cpu().numpy()
+        imps = _to_host(imps)
         self.last_final_imputations = imps
         if self._stores_artifacts():
             self._save_npz(f'imputations_{batch_idx}.npz', imputations=imps,

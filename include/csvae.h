@@ -527,6 +527,10 @@ int cs_debug_force_large_resample(int on);
 /* Test hook (no counterpart in the reference): 1 keeps the scalar log-weight kernel of the path for more than 64
  * proposals per example where its 16-byte-access form would run; both give the same bits. */
 int cs_debug_force_scalar_logw(int on);
+/* Test hook (no counterpart in the reference): matrix-kernel convolutions of launches that would leave half the CUs
+ * without a workgroup run in small blocks (32 output channels each) when a block has at least `steps` (tap,
+ * 32-channel chunk) steps; 0 keeps the large blocks for every launch.  Returns the previous value (default 18). */
+int cs_debug_set_small_launch_steps(int steps);
 /* Test hook (no counterpart in the reference): launches of the fused MLP in the fp16 split of up to 512 row tiles run
  * in a kernel that gives a row tile to a workgroup and splits each layer's output features over its wavefronts;
  * mode 0 disables that kernel, 1 uses it for every launch it has an instance for, -1 restores the size rule.

@@ -16,6 +16,16 @@ pytestmark = pytest.mark.gpu
 from tests.helpers import arith_fixture  # noqa: E402
 mlp_arith = arith_fixture()
 
+
+@pytest.fixture(autouse=True, params=["small_blocks_for_few_images", "large_blocks_always"])
+def block_shapes(request):
+    """Launches of a few images run in blocks of 32 output channels (so that they reach more CUs); every case here
+    runs with that rule and with the large blocks that full-size launches use."""
+    from vae_conditional_sampling_amd import _lib
+    prev = _lib.lib().cs_debug_set_small_launch_steps(18 if request.param.startswith("small") else 0)
+    yield
+    _lib.lib().cs_debug_set_small_launch_steps(prev)
+
 CONV_RTOL = 1e-5
 
 

@@ -16,6 +16,15 @@ pytestmark = pytest.mark.gpu
 RTOL = 1e-5   # of an image's largest output magnitude (float32-equivalent arithmetic, north-star tolerance)
 
 
+@pytest.fixture(autouse=True, params=["small_blocks_for_few_images", "large_blocks_always"])
+def block_shapes(request):
+    """Launches of a few images run in blocks of 32 output channels (so that they reach more CUs); every case here
+    runs with that rule and with the large blocks that full-size launches use."""
+    prev = _lib.lib().cs_debug_set_small_launch_steps(18 if request.param.startswith("small") else 0)
+    yield
+    _lib.lib().cs_debug_set_small_launch_steps(prev)
+
+
 def _program(c_in, c_out, hw, n_layers, seed, upsample_last=False, residual=False):
     g = torch.Generator().manual_seed(seed)
     out_hw = hw * (2 if upsample_last else 1)

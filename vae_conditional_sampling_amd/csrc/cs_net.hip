@@ -1794,6 +1794,9 @@ __global__ void __launch_bounds__(256) cs_image_amax_kernel(const float* x, int6
 
 inline unsigned blocks_for(int64_t n) { return (unsigned)((n + 255) / 256); }
 bool g_conv_tail_split = getenv("CSVAE_NO_TAIL_SPLIT") == nullptr;  // measurements without the second launch
+// launches that do not fill one round of CUs take the small blocks when a block has at least this many (tap, 32-channel
+// chunk) steps (0: never)
+int g_conv_small_launch_steps = getenv("CSVAE_SMALL_LAUNCH_STEPS") ? atoi(getenv("CSVAE_SMALL_LAUNCH_STEPS")) : 18;
 // measurements with every per-image maximum taken by the reduction pass instead of the producing layers' epilogues
 bool g_conv_fused_amax = getenv("CSVAE_NO_FUSED_AMAX") == nullptr;
 // fp16 split, same-size 64-channel layers: 256-pixel blocks of 4 waves, two to a CU (74 KB of LDS each), so that one
@@ -1952,12 +1955,25 @@ int launch_conv_mfma(const CsConvArgs& a, hipStream_t stream) {
         if (rc != CS_OK) return rc;
         return halo(a2, true);
       }
+      // A launch of a few images (the reference's image configurations sample 10 - 20 examples at a time) leaves most
+      // CUs idle while each block streams the weights of 64 - 128 output channels through its own loop: the small blocks
+      // (32 output channels, 128 pixels, three to a CU) put the same work on up to eight times as many CUs.
+      const int64_t nsmall = (a.npix + 127) / 128 * (a.cout_p / 32) * (phases4 ? 4 : 1);
+      if (big != 3 && nblocks * 2 <= ncu[dev] && nsmall <= 3 * (int64_t)ncu[dev] && g_conv_small_launch_steps > 0 &&
+          (a.cin >> 5) * (phases4 ? 4 : 9) >= g_conv_small_launch_steps)
+        return halo(a, true);
       return halo(a, false);
     } else if (a.w3h != nullptr && a.in_amax != nullptr) {  // generic kernel, fp16 split
-      if (a.cout_p % 128 == 0) {
+      // channel tiles per block: 4 or 2 where the channel count allows, fewer while the launch would leave half the CUs
+      // without a block (a few images: more blocks, each with a shorter pass over the weights)
+      static int ncu[64] = {};
+      if (!ncu[dev]) CS_HIP(hipDeviceGetAttribute(&ncu[dev], hipDeviceAttributeMultiprocessorCount, dev));
+      int ct = a.cout_p % 128 == 0 ? 4 : a.cout_p % 64 == 0 ? 2 : 1;
+      while (ct > 1 && g_conv_small_launch_steps > 0 && (int64_t)gx * (a.cout_p / (32 * ct)) * 2 <= ncu[dev]) ct >>= 1;
+      if (ct == 4) {
         constexpr int CT_ = 4;
         CS_CONV3_LAUNCH((cs_conv_mfma_split_kernel<CT_, 2>), (size_t)(128 + CT_ * 32) * 128);
-      } else if (a.cout_p % 64 == 0) {
+      } else if (ct == 2) {
         constexpr int CT_ = 2;
         CS_CONV3_LAUNCH((cs_conv_mfma_split_kernel<CT_, 2>), (size_t)(128 + CT_ * 32) * 128);
       } else {
@@ -2220,6 +2236,12 @@ int cs_dec_stage_launch(const CsMlpArgs& a, int64_t row0, int64_t rows, hipStrea
   hipLaunchKernelGGL(cs_dec_stage_kernel, dim3(blocks_for(n)), dim3(256), 0, stream, a, row0, rows);
   CS_HIP(hipGetLastError());
   return CS_OK;
+}
+
+extern "C" int cs_debug_set_small_launch_steps(int steps) {
+  const int prev = g_conv_small_launch_steps;
+  g_conv_small_launch_steps = steps;
+  return prev;
 }
 
 extern "C" int cs_debug_set_workspace_budget(int64_t bytes) {

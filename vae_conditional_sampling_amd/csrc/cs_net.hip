@@ -1963,32 +1963,24 @@ int launch_conv_mfma(const CsConvArgs& a, hipStream_t stream) {
           (a.cin >> 5) * (phases4 ? 4 : 9) >= g_conv_small_launch_steps)
         return halo(a, true);
       return halo(a, false);
-    } else if (a.w3h != nullptr && a.in_amax != nullptr) {  // generic kernel, fp16 split
-      // channel tiles per block: 4 or 2 where the channel count allows, fewer while the launch would leave half the CUs
-      // without a block (a few images: more blocks, each with a shorter pass over the weights)
+    } else {
+      // generic kernel.  Channel tiles per block: 4 or 2 where the channel count allows, fewer while the launch would
+      // leave half the CUs without a block (a few rows: more blocks, each with a shorter pass over the weights)
       static int ncu[64] = {};
       if (!ncu[dev]) CS_HIP(hipDeviceGetAttribute(&ncu[dev], hipDeviceAttributeMultiprocessorCount, dev));
       int ct = a.cout_p % 128 == 0 ? 4 : a.cout_p % 64 == 0 ? 2 : 1;
       while (ct > 1 && g_conv_small_launch_steps > 0 && (int64_t)gx * (a.cout_p / (32 * ct)) * 2 <= ncu[dev]) ct >>= 1;
-      if (ct == 4) {
-        constexpr int CT_ = 4;
-        CS_CONV3_LAUNCH((cs_conv_mfma_split_kernel<CT_, 2>), (size_t)(128 + CT_ * 32) * 128);
-      } else if (ct == 2) {
-        constexpr int CT_ = 2;
-        CS_CONV3_LAUNCH((cs_conv_mfma_split_kernel<CT_, 2>), (size_t)(128 + CT_ * 32) * 128);
-      } else {
-        constexpr int CT_ = 1;
-        CS_CONV3_LAUNCH((cs_conv_mfma_split_kernel<CT_, 2>), (size_t)(128 + CT_ * 32) * 128);
-      }
-    } else if (a.cout_p % 128 == 0) {
-      constexpr int CT_ = 4;
-      CS_CONV3_LAUNCH((cs_conv_mfma_split_kernel<CT_>), (size_t)(128 + CT_ * 32) * 192);
-    } else if (a.cout_p % 64 == 0) {
-      constexpr int CT_ = 2;
-      CS_CONV3_LAUNCH((cs_conv_mfma_split_kernel<CT_>), (size_t)(128 + CT_ * 32) * 192);
-    } else {
-      constexpr int CT_ = 1;
-      CS_CONV3_LAUNCH((cs_conv_mfma_split_kernel<CT_>), (size_t)(128 + CT_ * 32) * 192);
+      const bool half = a.w3h != nullptr && a.in_amax != nullptr;  // fp16 split
+#define CS_GENERIC_LAUNCH(CTV_)                                                                            \
+  do {                                                                                                     \
+    constexpr int CT_ = CTV_;                                                                              \
+    if (half) CS_CONV3_LAUNCH((cs_conv_mfma_split_kernel<CT_, 2>), (size_t)(128 + CT_ * 32) * 128);        \
+    else CS_CONV3_LAUNCH((cs_conv_mfma_split_kernel<CT_>), (size_t)(128 + CT_ * 32) * 192);                \
+  } while (0)
+      if (ct == 4) CS_GENERIC_LAUNCH(4);
+      else if (ct == 2) CS_GENERIC_LAUNCH(2);
+      else CS_GENERIC_LAUNCH(1);
+#undef CS_GENERIC_LAUNCH
     }
 #undef CS_CONV3_LAUNCH
 #undef CS_HALO3_LAUNCH

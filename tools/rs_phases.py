@@ -4,7 +4,7 @@
 Needs a library whose cs_lair.hip was compiled with -DCS_RS_PROFILE (the kernel then overwrites
 ess[] with the phase durations of each wavefront); not part of the product build.
 
-    python tools/rs_phases.py [miniboone|hepmass|gas] [B]
+    CSVAE_EXP_LIB=<that library> python tools/rs_phases.py [miniboone|hepmass|gas] [B] [examples per wavefront]
 """
 import ctypes as C
 import os
@@ -20,6 +20,8 @@ def main():
     name = sys.argv[1] if len(sys.argv) > 1 else "miniboone"
     B = int(sys.argv[2]) if len(sys.argv) > 2 else 65536
     from vae_conditional_sampling_amd import _lib
+    if os.environ.get("CSVAE_EXP_LIB"):   # the library built with -DCS_RS_PROFILE (this tool only)
+        _lib.LIB_PATH = os.path.abspath(os.environ["CSVAE_EXP_LIB"])
     from vae_conditional_sampling_amd.models import VAE, ResidualFCNetwork
     from vae_conditional_sampling_amd.sampling import engine
     w = bench.WORKLOADS[name]

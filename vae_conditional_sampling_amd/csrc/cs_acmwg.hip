@@ -483,7 +483,8 @@ extern "C" int cs_acmwg_run(const cs_mlp_t* enc, const cs_mlp_t* dec, const cs_a
                             void* stream) {
   CS_REQUIRE(c0 && b0 && T >= 0, "bad argument");
   if (int rc = check_acmwg(c0, b0)) return rc;
-  if (int rc = cs_observe_check(obs, c0->latent_dist)) return rc;
+  CsObserver observer;
+  if (int rc = observer.begin(enc, obs, c0->B, c0->K, c0->D, c0->Zd, c0->latent_dist)) return rc;
   const int64_t chains = (int64_t)c0->B * c0->K;
   const int64_t n_z = chains * c0->Zd, n_x = chains * c0->D;
   const bool use_hist = !(c0->flags & CS_MWG_PROPOSE_FROM_CURRENT);
@@ -505,17 +506,22 @@ extern "C" int cs_acmwg_run(const cs_mlp_t* enc, const cs_mlp_t* dec, const cs_a
     }
     cs_rng rt = r;
     rt.iteration = r.iteration + (uint32_t)t;
-    if (int rc = cs_acmwg_step(enc, dec, &c, &b, &rt, stream)) return rc;
+    int rc = cs_acmwg_step(enc, dec, &c, &b, &rt, stream);
     if (use_hist) {
       c.hist_tail = (c.hist_tail + 1) % c.hist_len;
       if (c.hist_tail == c.hist_len - 1) c.hist_full = 1;
     }
-    if (out && out->Z_store && chains)
-      CS_HIP(hipMemcpyAsync(out->Z_store + t * n_z, b.Z_old, (size_t)n_z * sizeof(float), hipMemcpyDeviceToDevice,
-                            (hipStream_t)stream));
-    if (int rc = cs_observe_iteration(enc, obs, t, b.X, b.M, c.B, c.K, c.D, c.Zd, c.latent_dist, stream)) return rc;
+    if (rc == CS_OK && out && out->Z_store && chains &&
+        hipMemcpyAsync(out->Z_store + t * n_z, b.Z_old, (size_t)n_z * sizeof(float), hipMemcpyDeviceToDevice,
+                       (hipStream_t)stream) != hipSuccess)
+      rc = cs_fail(CS_EHIP, "copy of the chain latents into Z_store failed");
+    if (rc == CS_OK) rc = observer.iteration(t, b.X, b.M, (hipStream_t)stream);
+    if (rc != CS_OK) {
+      (void)observer.finish((hipStream_t)stream);
+      return rc;
+    }
   }
-  return CS_OK;
+  return observer.finish((hipStream_t)stream);
 }
 
 // LAIR's historical proposals: Xc[b] = (X[b, 0..K), ring[slots[h], b, chain] for h < H).

@@ -845,10 +845,9 @@ extern "C" int cs_lair_run_observed(const cs_mlp_t* enc, const cs_mlp_t* dec, co
                                     void* stream) {
   CS_REQUIRE(c && b0 && T >= 0, "bad argument");
   if (int rc = check_cfg(c, b0)) return rc;
-  if (obs) {
-    CS_REQUIRE(!b0->X_out && (c->K_impute == 0 || c->K_impute == c->K), "an observed run imputes all chains in place");
-    if (int rc = cs_observe_check(obs, c->latent_dist)) return rc;
-  }
+  if (obs) CS_REQUIRE(!b0->X_out && (c->K_impute == 0 || c->K_impute == c->K), "an observed run imputes all chains in place");
+  CsObserver observer;
+  if (int rc = observer.begin(enc, obs, c->B, c->K, c->D, c->Zd, c->latent_dist)) return rc;
   const int64_t B = c->B, Kp = c->K + c->R, I = c->I, Zd = c->Zd;
   const int64_t Kimp = c->K_impute > 0 ? c->K_impute : c->K;
   const int64_t Kg = c->glr_pad_to > 0 && c->scheme == CS_RS_GLR ? c->glr_pad_to : Kp;
@@ -878,10 +877,14 @@ extern "C" int cs_lair_run_observed(const cs_mlp_t* enc, const cs_mlp_t* dec, co
     }
     cs_rng rt = r;
     rt.iteration = r.iteration + (uint32_t)t;
-    if (int rc = cs_lair_step(enc, dec, c, &b, &rt, stream)) return rc;
-    if (int rc = cs_observe_iteration(enc, obs, t, b.X, b.M, B, c->K, c->D, c->Zd, c->latent_dist, stream)) return rc;
+    int rc = cs_lair_step(enc, dec, c, &b, &rt, stream);
+    if (rc == CS_OK) rc = observer.iteration(t, b.X, b.M, (hipStream_t)stream);
+    if (rc != CS_OK) {
+      (void)observer.finish((hipStream_t)stream);
+      return rc;
+    }
   }
-  return CS_OK;
+  return observer.finish((hipStream_t)stream);
 }
 
 // ----------------------------------------------------------------------------------------

@@ -7,7 +7,9 @@
 #include "cs_common.h"
 #include "cs_mlp.h"
 
+#include <cstdlib>
 #include <cstring>
+#include <mutex>
 
 namespace {
 
@@ -151,26 +153,57 @@ extern "C" int cs_latent_wasserstein(const float* q_imp, const float* q_true, in
 // The per-iteration work of the harness inside a run of several iterations (cs_run_observe): keep the
 // imputations, compute the diagnostics (test_step_vae_sampling.py:386-391, 431-445).
 // ----------------------------------------------------------------------------------------
-int cs_observe_check(const cs_run_observe* o, int32_t latent_dist) {
+namespace {
+struct SideStream { hipStream_t stream = nullptr; hipEvent_t copied = nullptr, done = nullptr; };
+SideStream g_side[64];
+std::mutex g_side_mutex;
+const bool g_observe_inline = getenv("CSVAE_OBSERVE_INLINE") != nullptr;  // measurements without the second stream
+}  // namespace
+
+int CsObserver::begin(const cs_mlp_t* enc_, const cs_run_observe* o_, int64_t B_, int32_t K_, int32_t D_, int32_t Zd_,
+                      int32_t latent_dist_) {
+  o = o_; enc = enc_; B = B_; K = K_; D = D_; Zd = Zd_; latent_dist = latent_dist_;
+  side = nullptr;
   if (!o) return CS_OK;
   CS_REQUIRE(!(o->rmse_store || o->mae_store) || o->X_true, "rmse / mae stores need X_true");
   if (o->wass_store) {
-    CS_REQUIRE(o->q_true && o->q_work, "the latent distance needs q_true and q_work");
+    CS_REQUIRE(o->q_true && o->q_work && enc, "the latent distance needs the encoder, q_true and q_work");
     if (latent_dist == CS_DIST_BETA) return cs_fail(CS_EUNSUPPORTED, "latent Wasserstein distance: Gaussian posteriors only");
   }
+  const bool diagnostics = o->rmse_store || o->mae_store || o->wass_store;
+  if (!diagnostics || !o->X_store || (o->wass_store && enc->prog) || g_observe_inline || B == 0) return CS_OK;
+  int dev = 0;
+  CS_HIP(hipGetDevice(&dev));
+  CS_REQUIRE(dev >= 0 && dev < 64, "device index out of range");
+  std::lock_guard<std::mutex> lock(g_side_mutex);
+  SideStream& s = g_side[dev];
+  if (!s.stream) {
+    CS_HIP(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+    CS_HIP(hipEventCreateWithFlags(&s.copied, hipEventDisableTiming));
+    CS_HIP(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+  }
+  side = s.stream; copied = s.copied; done = s.done;
   return CS_OK;
 }
 
-int cs_observe_iteration(const cs_mlp_t* enc, const cs_run_observe* o, int32_t t, const float* X, const uint8_t* M,
-                         int64_t B, int32_t K, int32_t D, int32_t Zd, int32_t latent_dist, void* stream) {
+int CsObserver::iteration(int32_t t, const float* X, const uint8_t* M, hipStream_t stream) {
   if (!o || B == 0) return CS_OK;
   const int64_t chains = B * K;
-  if (o->X_store)
-    CS_HIP(hipMemcpyAsync(o->X_store + (int64_t)t * chains * D, X, (size_t)chains * D * sizeof(float),
-                          hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  const float* Xd = X;            // what the diagnostics read
+  hipStream_t ds = stream;        // and where
+  if (o->X_store) {
+    float* kept = o->X_store + (int64_t)t * chains * D;
+    CS_HIP(hipMemcpyAsync(kept, X, (size_t)chains * D * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    if (side) {
+      CS_HIP(hipEventRecord(copied, stream));
+      CS_HIP(hipStreamWaitEvent(side, copied, 0));
+      Xd = kept;
+      ds = side;
+    }
+  }
   if (o->rmse_store || o->mae_store)
-    if (int rc = cs_imputation_errors(X, o->X_true, M, B, K, D, o->rmse_store ? o->rmse_store + (int64_t)t * chains : nullptr,
-                                      o->mae_store ? o->mae_store + (int64_t)t * chains : nullptr, stream))
+    if (int rc = cs_imputation_errors(Xd, o->X_true, M, B, K, D, o->rmse_store ? o->rmse_store + (int64_t)t * chains : nullptr,
+                                      o->mae_store ? o->mae_store + (int64_t)t * chains : nullptr, ds))
       return rc;
   if (o->wass_store) {
     // VAE.compute_var_distr of the imputed data (imputation_metrics.py:203-207): the encoder on X as it is
@@ -180,9 +213,16 @@ int cs_observe_iteration(const cs_mlp_t* enc, const cs_run_observe* o, int32_t t
     c.gen_dist = CS_DIST_NORMAL; c.weight_alpha = 1.0f; c.prior = CS_PRIOR_STD_NORMAL;
     cs_lair_bufs b;
     std::memset(&b, 0, sizeof(b));
-    b.X = const_cast<float*>(X); b.q = o->q_work;
-    if (int rc = cs_lair_encode(enc, &c, &b, stream)) return rc;
-    if (int rc = cs_latent_wasserstein(o->q_work, o->q_true, B, K, Zd, o->wass_store + (int64_t)t * chains, stream)) return rc;
+    b.X = const_cast<float*>(Xd); b.q = o->q_work;
+    if (int rc = cs_lair_encode(enc, &c, &b, ds)) return rc;
+    if (int rc = cs_latent_wasserstein(o->q_work, o->q_true, B, K, Zd, o->wass_store + (int64_t)t * chains, ds)) return rc;
   }
+  return CS_OK;
+}
+
+int CsObserver::finish(hipStream_t stream) {
+  if (!side) return CS_OK;
+  CS_HIP(hipEventRecord(done, side));
+  CS_HIP(hipStreamWaitEvent(stream, done, 0));
   return CS_OK;
 }

@@ -80,10 +80,21 @@ struct CsMlpArgs {
 
 int cs_mlp_launch(const CsMlpArgs& a, hipStream_t stream);
 
-// The harness's per-iteration work of a run (cs_run_observe), after iteration t left X[B,K,D]: defined with the
-// diagnostics kernels.
-int cs_observe_check(const cs_run_observe* o, int32_t latent_dist);
-int cs_observe_iteration(const cs_mlp_t* enc, const cs_run_observe* o, int32_t t, const float* X, const uint8_t* M,
-                         int64_t B, int32_t K, int32_t D, int32_t Zd, int32_t latent_dist, void* stream);
+// The harness's per-iteration work of a run (cs_run_observe), defined with the diagnostics kernels.  begin() checks
+// the stores and decides where the diagnostics run: on a stream of the library's own beside the run's (they read the
+// kept copy X_store[t], which nothing overwrites, so iteration t + 1 need not wait for them) when the imputations are
+// kept and the encoder is a fused-MLP handle (a layer program's workspace cannot serve two streams), else in the
+// run's stream.  finish() makes the run's stream wait for what is still in flight.
+struct CsObserver {
+  const cs_run_observe* o = nullptr;
+  const cs_mlp_t* enc = nullptr;
+  int64_t B = 0;
+  int32_t K = 0, D = 0, Zd = 0, latent_dist = 0;
+  hipStream_t side = nullptr;     // null: everything in the run's stream
+  hipEvent_t copied = nullptr, done = nullptr;
+  int begin(const cs_mlp_t* enc, const cs_run_observe* o, int64_t B, int32_t K, int32_t D, int32_t Zd, int32_t latent_dist);
+  int iteration(int32_t t, const float* X, const uint8_t* M, hipStream_t stream);
+  int finish(hipStream_t stream);
+};
 // CS_ARITH_* in force for fused-MLP launches (cs_set_mlp_arith, or CSVAE_MLP_ARITH at first use)
 int cs_mlp_arith();

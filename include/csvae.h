@@ -267,7 +267,9 @@ int cs_lair_run(const cs_mlp_t* enc, const cs_mlp_t* dec, const cs_lair_cfg* cfg
  *   wass_store[t] = cs_latent_wasserstein(encoder posterior of X, q_true)      (NULL: not computed; Gaussian
  *                   posteriors only; q_work[B,K,2,Zd] is the workspace of the encoder pass, q_true[B,2,Zd] the
  *                   posterior of the true data, encoded once by the caller)
- * each store holding T blocks of the per-iteration shape [B,K]. */
+ * each store holding T blocks of the per-iteration shape [B,K].  When X_store is given (and the encoder is a fused-MLP
+ * handle, or wass_store is NULL) the diagnostics read the kept copies on a stream of the library's own beside
+ * `stream`, which waits for them before the call returns: the caller sees ordinary stream order. */
 typedef struct {
   float* X_store;
   const float* X_true; /* [B,D]; with rmse_store / mae_store */
@@ -418,6 +420,11 @@ int cs_latent_wasserstein(const float* q_imp, const float* q_true, int64_t B, in
  * reads.  `lookback`: how many bytes before src belong to the same stream and are readable at src - lookback.
  * Returns the number of bytes written to dst, or -1 (dst_cap too small: n + n/8 + 64 always suffices). */
 int64_t cs_deflate_rows(const uint8_t* src, int64_t n, int32_t stride, int64_t lookback, uint8_t* dst, int64_t dst_cap);
+/* HOST functions: CRC-32 of the zip container (zlib's crc32: cs_crc32(p, n, 0) of a whole buffer, or continued from
+ * `crc`), and the checksum of two adjacent pieces from their own checksums and the length of the second, so that the
+ * threads that deflate the pieces of a member also checksum them. */
+uint32_t cs_crc32(const uint8_t* p, int64_t n, uint32_t crc);
+uint32_t cs_crc32_combine(uint32_t crc1, uint32_t crc2, int64_t len2);
 
 /* gen[rows,2,D] (mean, scale), [rows,D] (Bernoulli logits) or [rows,3,D] (Student-t: loc, scale, df) = generator parameterisation of
  * generator_network(Z[rows,Zd]) (vae.py:171-172,203-256). */

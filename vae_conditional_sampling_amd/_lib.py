@@ -211,6 +211,10 @@ def lib():
     L.cs_mlp_set_arith.argtypes = [vp, i32]
     L.cs_mlp_get_arith.argtypes = [vp]
     L.cs_net_reserve.argtypes = [vp, i64]
+    L.cs_crc32.restype = u32
+    L.cs_crc32.argtypes = [vp, i64, u32]
+    L.cs_crc32_combine.restype = u32
+    L.cs_crc32_combine.argtypes = [u32, u32, i64]
     L.cs_deflate_rows.restype = i64
     L.cs_deflate_rows.argtypes = [vp, i64, i32, i64, vp, i64]
     L.cs_imputation_errors.argtypes = [vp, vp, vp, i64, i32, i32, vp, vp, vp]

@@ -362,3 +362,73 @@ extern "C" int64_t cs_deflate_rows(const uint8_t* src, int64_t n, int32_t stride
   }
   return (int64_t)(w.p - dst);
 }
+
+// ----------------------------------------------------------------------------------------
+// CRC-32 (the zip container's checksum of a member's uncompressed bytes; polynomial 0xEDB88320, as zlib's crc32) of
+// a piece, and the combination of the checksums of two adjacent pieces: the writer's threads checksum the pieces
+// they deflate, and the member's checksum is folded together from theirs instead of one thread reading the whole
+// array again.
+// ----------------------------------------------------------------------------------------
+namespace {
+struct CrcTables {
+  uint32_t t[8][256];
+  CrcTables() {
+    for (uint32_t i = 0; i < 256; ++i) {
+      uint32_t c = i;
+      for (int k = 0; k < 8; ++k) c = (c & 1) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+      t[0][i] = c;
+    }
+    for (uint32_t i = 0; i < 256; ++i)
+      for (int k = 1; k < 8; ++k) t[k][i] = t[0][t[k - 1][i] & 0xFF] ^ (t[k - 1][i] >> 8);
+  }
+};
+// a 32 x 32 matrix over GF(2) (one column per word) times a vector
+inline uint32_t gf2_times(const uint32_t* mat, uint32_t vec) {
+  uint32_t sum = 0;
+  for (; vec; vec >>= 1, ++mat)
+    if (vec & 1) sum ^= *mat;
+  return sum;
+}
+inline void gf2_square(uint32_t* square, const uint32_t* mat) {
+  for (int n = 0; n < 32; ++n) square[n] = gf2_times(mat, mat[n]);
+}
+}  // namespace
+
+extern "C" uint32_t cs_crc32(const uint8_t* p, int64_t n, uint32_t crc) {
+  static const CrcTables T;
+  uint32_t c = ~crc;
+  while (n > 0 && ((uintptr_t)p & 7)) { c = T.t[0][(c ^ *p++) & 0xFF] ^ (c >> 8); --n; }
+  while (n >= 8) {   // eight bytes per step (little-endian host)
+    uint64_t w;
+    std::memcpy(&w, p, 8);
+    w ^= c;
+    c = T.t[7][w & 0xFF] ^ T.t[6][(w >> 8) & 0xFF] ^ T.t[5][(w >> 16) & 0xFF] ^ T.t[4][(w >> 24) & 0xFF] ^
+        T.t[3][(w >> 32) & 0xFF] ^ T.t[2][(w >> 40) & 0xFF] ^ T.t[1][(w >> 48) & 0xFF] ^ T.t[0][(w >> 56) & 0xFF];
+    p += 8;
+    n -= 8;
+  }
+  while (n-- > 0) c = T.t[0][(c ^ *p++) & 0xFF] ^ (c >> 8);
+  return ~c;
+}
+
+// crc of A followed by B from crc(A), crc(B) and the length of B: appending len2 zero bytes to A is a linear map of
+// its checksum register, applied by repeated squaring of the one-zero-bit operator.
+extern "C" uint32_t cs_crc32_combine(uint32_t crc1, uint32_t crc2, int64_t len2) {
+  if (len2 <= 0) return crc1;
+  uint32_t even[32], odd[32];
+  odd[0] = 0xEDB88320u;   // the operator of one zero bit
+  uint32_t row = 1;
+  for (int n = 1; n < 32; ++n) { odd[n] = row; row <<= 1; }
+  gf2_square(even, odd);  // two zero bits
+  gf2_square(odd, even);  // four
+  do {                    // the first squaring below gives the operator of one zero byte
+    gf2_square(even, odd);
+    if (len2 & 1) crc1 = gf2_times(even, crc1);
+    len2 >>= 1;
+    if (!len2) break;
+    gf2_square(odd, even);
+    if (len2 & 1) crc1 = gf2_times(odd, crc1);
+    len2 >>= 1;
+  } while (len2);
+  return crc1 ^ crc2;
+}

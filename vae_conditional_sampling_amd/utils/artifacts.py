@@ -55,20 +55,34 @@ def row_stride_of(arr):
     return stride if 1 <= stride <= 32768 else None
 
 
+def _crc32(data):
+    """CRC-32 of a contiguous buffer (cs_crc32: the zip container's checksum, without the interpreter lock)."""
+    src = np.frombuffer(data, dtype=np.uint8)
+    return _lib.lib().cs_crc32(src.ctypes.data if src.size else None, src.size, 0)
+
+
 class _PieceDeflate:
     """Stands in for the compressor object of an open zip member: ``compress`` deflates its input in
-    independent ``_PIECE``-sized pieces on the pool, ``flush`` closes the stream."""
+    independent ``_PIECE``-sized pieces on the pool, ``flush`` closes the stream.  The threads also checksum their
+    pieces; ``crc`` is the checksum of everything compressed so far, continued from ``crc0``."""
 
-    def __init__(self, pool, level):
-        self._pool, self._level = pool, level
+    def __init__(self, pool, level, crc0=0):
+        self._pool, self._level, self.crc = pool, level, crc0
 
-    def _one(self, piece):
+    def _deflate(self, piece, offset):
         c = zlib.compressobj(self._level, zlib.DEFLATED, -15)
         return c.compress(piece) + c.flush(zlib.Z_FULL_FLUSH)
 
-    def compress(self, data):
+    def _one(self, args):
+        piece, offset = args
+        return self._deflate(piece, offset), _crc32(piece), len(piece)
+
+    def compress(self, data, offset=0):
         mv = memoryview(data)
-        return b"".join(self._pool.map(self._one, [mv[i:i + _PIECE] for i in range(0, len(mv), _PIECE)]))
+        parts = list(self._pool.map(self._one, [(mv[i:i + _PIECE], offset + i) for i in range(0, len(mv), _PIECE)]))
+        for _, crc, n in parts:
+            self.crc = _lib.lib().cs_crc32_combine(self.crc, crc, n)
+        return b"".join(p[0] for p in parts)
 
     def flush(self):
         return zlib.compressobj(self._level, zlib.DEFLATED, -15).flush(zlib.Z_FINISH)
@@ -76,18 +90,15 @@ class _PieceDeflate:
 
 class _RowDeflate(_PieceDeflate):
     """The same for an array of short rows: the pieces go through cs_deflate_rows.  ``compress`` is called with
-    consecutive slices of one contiguous buffer, so a piece may match into the bytes before it."""
+    consecutive slices of one contiguous buffer (``offset``: where the slice starts in it), so a piece may match into
+    the bytes before it."""
 
-    def __init__(self, pool, level, stride):
-        super().__init__(pool, level)
-        self._stride, self._done = stride, 0
+    def __init__(self, pool, level, stride, crc0=0):
+        super().__init__(pool, level, crc0)
+        self._stride = stride
 
-    def compress(self, data):
-        mv = memoryview(data)
-        base = self._done
-        self._done += len(mv)
-        return b"".join(self._pool.map(lambda i: deflate_rows(mv[i:i + _PIECE], self._stride, base + i),
-                                       range(0, len(mv), _PIECE)))
+    def _deflate(self, piece, offset):
+        return deflate_rows(piece, self._stride, offset)
 
 
 def savez_compressed_parallel(path, pool, level=6, **arrays):
@@ -105,12 +116,18 @@ def savez_compressed_parallel(path, pool, level=6, **arrays):
                 arr = arr if arr.flags.c_contiguous else np.ascontiguousarray(arr)   # (keeps 0-d arrays 0-d)
                 f._compressor = _PieceDeflate(pool, level)
                 np.lib.format.write_array_header_1_0(f, np.lib.format.header_data_from_array_1_0(arr))
+                # From here on the stream is the array's memory.  The member's bookkeeping (what ZipFile's write()
+                # does, with the checksum taken by one thread over the whole array) is done here from the pieces'.
                 stride = row_stride_of(arr)
-                if stride:   # from here on the stream is the array's memory: a piece may match into the bytes before it
-                    f._compressor = _RowDeflate(pool, level, stride)
+                comp = _RowDeflate(pool, level, stride, f._crc) if stride else _PieceDeflate(pool, level, f._crc)
+                f._compressor = comp
                 raw = memoryview(arr.reshape(-1)).cast("B") if arr.size else memoryview(b"")
                 for i in range(0, len(raw), _SLICE):
-                    f.write(raw[i:i + _SLICE])
+                    out = comp.compress(raw[i:i + _SLICE], i)
+                    f._file_size += len(raw[i:i + _SLICE])
+                    f._compress_size += len(out)
+                    f._fileobj.write(out)
+                f._crc = comp.crc
 
 
 class AsyncNpzWriter:

@@ -397,6 +397,29 @@ def test_row_encoder_writes_what_numpy_reads(tmp_path):
     assert zlib.decompress(piece, -15) == raw
 
 
+def test_crc32_and_its_combination_match_zlib():
+    """cs_crc32 / cs_crc32_combine (host functions of the library) against zlib.crc32: unaligned starts, lengths around
+    the 8-byte step, continuation from a running value, and pieces folded together in order."""
+    import zlib
+
+    from vae_conditional_sampling_amd import _lib
+    L = _lib.lib()
+    rs = np.random.RandomState(3)
+    for n in (0, 1, 7, 8, 9, 63, 1000, 123457):
+        b = rs.randint(0, 256, n).astype(np.uint8)
+        for off in (0, 3):
+            buf = np.empty(n + 8, np.uint8)
+            v = buf[off:off + n]
+            v[:] = b
+            assert L.cs_crc32(v.ctypes.data if n else None, n, 0) == zlib.crc32(b.tobytes())
+            assert L.cs_crc32(v.ctypes.data if n else None, n, 0xDEADBEEF) == zlib.crc32(b.tobytes(), 0xDEADBEEF)
+        cuts = sorted(set([0, n // 3, n // 2, n]))
+        crc = 0
+        for lo, hi in zip([0] + cuts, cuts + [n]):
+            crc = L.cs_crc32_combine(crc, zlib.crc32(b[lo:hi].tobytes()), hi - lo)
+        assert crc == zlib.crc32(b.tobytes())
+
+
 def test_sharded_artifact_merge_passes_switched_off_entries_through(tmp_path):
     """An option that is off is stored as an empty list in the artefact files (``latents`` without
     ``store_latents``), also where the example axis of that key is 0 (final-resampling files): merging shards,

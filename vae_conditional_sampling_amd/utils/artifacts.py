@@ -67,7 +67,7 @@ class _PieceDeflate:
     pieces; ``crc`` is the checksum of everything compressed so far, continued from ``crc0``."""
 
     def __init__(self, pool, level, crc0=0):
-        self._pool, self._level, self.crc = pool, level, crc0
+        self._pool, self._level, self.crc, self._done = pool, level, crc0, 0
 
     def _deflate(self, piece, offset):
         c = zlib.compressobj(self._level, zlib.DEFLATED, -15)
@@ -77,8 +77,10 @@ class _PieceDeflate:
         piece, offset = args
         return self._deflate(piece, offset), _crc32(piece), len(piece)
 
-    def compress(self, data, offset=0):
+    def compress(self, data, offset=None):
         mv = memoryview(data)
+        offset = self._done if offset is None else offset   # (a caller that only knows write(): consecutive slices)
+        self._done = offset + len(mv)
         parts = list(self._pool.map(self._one, [(mv[i:i + _PIECE], offset + i) for i in range(0, len(mv), _PIECE)]))
         for _, crc, n in parts:
             self.crc = _lib.lib().cs_crc32_combine(self.crc, crc, n)
@@ -119,15 +121,21 @@ def savez_compressed_parallel(path, pool, level=6, **arrays):
                 # From here on the stream is the array's memory.  The member's bookkeeping (what ZipFile's write()
                 # does, with the checksum taken by one thread over the whole array) is done here from the pieces'.
                 stride = row_stride_of(arr)
-                comp = _RowDeflate(pool, level, stride, f._crc) if stride else _PieceDeflate(pool, level, f._crc)
+                crc0 = getattr(f, "_crc", 0)
+                comp = _RowDeflate(pool, level, stride, crc0) if stride else _PieceDeflate(pool, level, crc0)
                 f._compressor = comp
                 raw = memoryview(arr.reshape(-1)).cast("B") if arr.size else memoryview(b"")
+                own_books = all(hasattr(f, a) for a in ("_crc", "_file_size", "_compress_size", "_fileobj"))
                 for i in range(0, len(raw), _SLICE):
+                    if not own_books:        # another zipfile implementation: its write() keeps the books
+                        f.write(raw[i:i + _SLICE])
+                        continue
                     out = comp.compress(raw[i:i + _SLICE], i)
                     f._file_size += len(raw[i:i + _SLICE])
                     f._compress_size += len(out)
                     f._fileobj.write(out)
-                f._crc = comp.crc
+                if own_books:
+                    f._crc = comp.crc
 
 
 class AsyncNpzWriter:

@@ -7,6 +7,7 @@
 //                            335-378, 380-458, 677-726, 804-834)
 #include "cs_lair.h"
 
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 
@@ -53,13 +54,14 @@ __global__ void __launch_bounds__(64) cs_lair_resample_kernel(const CsResampleAr
   const int QS = a.q_stride, ZS = a.z_stride;
   const int64_t b0 = (int64_t)blockIdx.x * E;            // first example of this wave
   const int ne = (int)((B - b0) < E ? (B - b0) : E);     // examples present
+  const bool beta_q = a.cfg.latent_dist == CS_DIST_BETA;
   float* l_loc = lds;                      // [E][QS]  (Kp*Zd used)
   float* l_2var = l_loc + E * QS;          // [E][QS]  1/(2*scale^2)
-  float* l_logs = l_2var + E * QS;         // [E][QS]  log(scale)
-  float* l_z = l_logs + E * QS;            // [E][S][ZS]
+  float* l_z = l_2var + E * QS;            // [E][S][ZS]
   int* l_idx = (int*)(l_z + E * S * ZS);   // [E][2*NS] resampled global indices (two draws)
   float* l_c = (float*)(l_idx + E * 2 * NS);  // [E][S][mixc] component log-densities
-  const bool beta_q = a.cfg.latent_dist == CS_DIST_BETA;
+  float* l_L = l_c + E * S * a.mixc;       // [E][Kp]  normal posteriors: a component's proposal-independent terms
+  float* l_logs = l_L + E * Kp;            // [E][QS]  Beta posteriors only: log-normaliser per dimension
   // -DCS_RS_PROFILE (debug builds only, see tools/rs_phases.py): the wavefront's clock at the phase
   // boundaries; the phase durations then overwrite the first entries of ess / tess / perplexity
 #ifdef CS_RS_PROFILE
@@ -82,7 +84,7 @@ __global__ void __launch_bounds__(64) cs_lair_resample_kernel(const CsResampleAr
       } else {
         o0 = loc;
         o1 = __builtin_amdgcn_rcpf(2.0f * (sc * sc));
-        o2 = cs_logf(sc);
+        o2 = 0.0f;   // (log(scale) is summed per component below, not staged)
       }
     };
     if (VEC) {
@@ -112,7 +114,7 @@ __global__ void __launch_bounds__(64) cs_lair_resample_kernel(const CsResampleAr
           const int o = eq * QS + j * Zd + 4 * dq;
           *(f32x4*)(l_loc + o) = f32x4{o0[0], o0[1], o0[2], o0[3]};
           *(f32x4*)(l_2var + o) = f32x4{o1[0], o1[1], o1[2], o1[3]};
-          *(f32x4*)(l_logs + o) = f32x4{o2[0], o2[1], o2[2], o2[3]};
+          if (beta_q) *(f32x4*)(l_logs + o) = f32x4{o2[0], o2[1], o2[2], o2[3]};
         }
       }
     } else {
@@ -120,7 +122,9 @@ __global__ void __launch_bounds__(64) cs_lair_resample_kernel(const CsResampleAr
         const int ej = cs_div(t, a.dZd), d = t - ej * Zd;  // ej = e*Kp + j
         const int e = cs_div(ej, a.dKp), j = ej - e * Kp;
         const int o = e * QS + j * Zd + d;
-        stage1(qb[(int64_t)ej * 2 * Zd + d], qb[(int64_t)ej * 2 * Zd + Zd + d], l_loc[o], l_2var[o], l_logs[o]);
+        float o2;
+        stage1(qb[(int64_t)ej * 2 * Zd + d], qb[(int64_t)ej * 2 * Zd + Zd + d], l_loc[o], l_2var[o], o2);
+        if (beta_q) l_logs[o] = o2;
       }
       for (int t = lane; t < ne * S * Zd; t += 64) {
         const int es = cs_div(t, a.dZd), d = t - es * Zd;
@@ -130,23 +134,28 @@ __global__ void __launch_bounds__(64) cs_lair_resample_kernel(const CsResampleAr
       }
     }
   }
-  __syncthreads();
   // Normal posteriors: the terms of a component's log-density that do not depend on the proposal,
   // L[e][j] = sum_d log(scale_jd) + Zd * log(sqrt(2 pi)), summed once per component (in order of d)
-  // instead of once per proposal; kept in the first entry of the component's log-scale row.
-  if (!beta_q) {
+  // instead of once per proposal.  Lane e*Kp + j takes its component's scales from q again (the staging loop
+  // has just pulled those lines in): staging the logarithms would cost a third array of the posteriors' size in
+  // LDS, which is what limits the number of resident wavefronts.
+  if (!beta_q && lane < ne * Kp) {
+    const float* sr = a.b.q + (b0 * Kp + lane) * 2 * Zd + Zd;
     float Lj = 0.0f;
-    const bool own = lane < ne * Kp;
-    const int ce = cs_div(lane, a.dKp), cj = lane - ce * Kp;
-    float* row = l_logs + ce * QS + cj * Zd;
-    if (own) {
-      for (int d = 0; d < Zd; ++d) Lj += row[d];
-      Lj += (float)Zd * CS_LOG_SQRT_2PI;
+    if (VEC) {
+      for (int d = 0; d < Zd; d += 4) {
+        const f32x4 sc = *(const f32x4*)(sr + d);
+        Lj += cs_logf(sc.x);
+        Lj += cs_logf(sc.y);
+        Lj += cs_logf(sc.z);
+        Lj += cs_logf(sc.w);
+      }
+    } else {
+      for (int d = 0; d < Zd; ++d) Lj += cs_logf(sr[d]);
     }
-    __syncthreads();
-    if (own) row[0] = Lj;
-    __syncthreads();
+    l_L[lane] = Lj + (float)Zd * CS_LOG_SQRT_2PI;
   }
+  __syncthreads();
   CS_TICK();
 
   // An example owns P lanes, P the power of two >= S, so that the reductions over its proposals are
@@ -254,13 +263,13 @@ __global__ void __launch_bounds__(64) cs_lair_resample_kernel(const CsResampleAr
             df = zz.z - lo.z; cj -= (df * df) * iv.z;
             df = zz.w - lo.w; cj -= (df * df) * iv.w;
           }
-          cj -= qls[0];
+          cj -= l_L[e * Kp + j];
         } else {
           for (int d = 0; d < Zd; ++d) {
             const float df = z[d] - qloc[d];
             cj -= (df * df) * q2v[d];
           }
-          cj -= qls[0];
+          cj -= l_L[e * Kp + j];
         }
       }
       l_c[t] = cj;
@@ -696,13 +705,19 @@ extern "C" int cs_lair_resample_impute(const cs_lair_cfg* c, const cs_lair_bufs*
   const int qn = a.Kp * c->Zd;
   a.q_stride = vec ? (((qn >> 2) | 1) << 2) : (qn | 1);
   a.z_stride = vec ? c->Zd + 4 : c->Zd + 1;
-  const int per_example = 3 * a.q_stride + a.S * a.z_stride + 2 * a.NS + a.S * a.mixc;  // floats of LDS
+  // floats of LDS: loc and 1/(2 var) rows (a third array of that size for Beta posteriors), latents, indices,
+  // component log-densities, per-component constants
+  const int per_example = (c->latent_dist == CS_DIST_BETA ? 3 : 2) * a.q_stride + a.S * a.z_stride + 2 * a.NS +
+                          a.S * a.mixc + a.Kp;
   a.P = 1; a.logP = 0;
   while (a.P < a.S) { a.P <<= 1; ++a.logP; }
   a.E = 64 / a.P;
-  // more examples per wavefront fill more lanes, but the LDS working set limits how many
-  // wavefronts are resident; ~12 KB per wavefront measured best (MiniBooNE shape)
-  while (a.E > 1 && (size_t)a.E * per_example * 4 > 12 * 1024) --a.E;
+  // more examples per wavefront fill more lanes, but the LDS working set limits how many wavefronts are resident
+  // and the kernel lives on hiding one wavefront's memory round trips behind the others: up to 10 KB per wavefront
+  // measured best (MiniBooNE: 4 examples of 5 proposals, 8.8 KB, 18 resident wavefronts per CU, 136 us per 65 536
+  // examples against 151 with 5 examples and 159 with 3; HEPMASS / GAS: 2 examples of 17 proposals, 9.9 KB)
+  static const int lds_kb = getenv("CSVAE_RS_LDS_KB") ? atoi(getenv("CSVAE_RS_LDS_KB")) : 10;  // (measurement switch)
+  while (a.E > 1 && (size_t)a.E * per_example * 4 > (size_t)lds_kb * 1024) --a.E;
   // small batches: fewer examples per wavefront, so that the launch spreads over the chip and the loops of a
   // wavefront (staging, imputation: a memory round trip per pass) are one pass long
   {

@@ -1,59 +1,38 @@
-"""Time of single same-size 3x3 convolution layers (the halo kernels) through a layer program of N equal layers.
-
-    python tools/bench_conv_layer.py [rows] [layers] [channels[:resolution],...]
-
-Shapes: the residual stages of the reference's ResNet encoders / decoders (channels x resolution).  Prints the time per
-layer and the algorithmic TFLOP/s (2 * 9 * cin * cout * H * W per image) against the arithmetic's ceiling.
-"""
+"""Time of one same-size 3x3 convolution layer (a one-layer program) against the number of images:
+python tools/bench_conv_layer.py [channels] [height=width] [rows ...]"""
+import os
 import sys
-import time
 
 import torch
 
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from vae_conditional_sampling_amd import _lib  # noqa: E402
 
-SHAPES = [(64, 28), (128, 14), (256, 7), (512, 4), (256, 4), (128, 7), (64, 14), (32, 14)]
-
-
-def main():
-    rows = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
-    nl = int(sys.argv[2]) if len(sys.argv) > 2 else 8
-    arith = _lib.get_mlp_arith()
-    peak = 157.3 if arith == "f32" else 2500.0 / 6
-    g = torch.Generator().manual_seed(0)
-    only = sys.argv[3].split(",") if len(sys.argv) > 3 else None
-    for c, hw in SHAPES:
-        if only is not None and str(c) not in only and f"{c}:{hw}" not in only:
-            continue
-        b = _lib.ProgramBuilder(c * hw * hw, c * hw * hw, 1)
-        w = torch.randn(c, c, 3, 3, generator=g) / (3 * c ** 0.5)
-        bias = torch.randn(c, generator=g) * 0.1
-        src = 0
-        for i in range(nl):
-            dst = _lib.CS_NET_BUF_OUT if i == nl - 1 else 1 + (i & 1)
-            b.conv(src, dst, w, bias, hin=hw, win=hw, relu=True)
-            src = dst
-        net = b.build()
-        x = torch.randn(rows, c * hw * hw, generator=g).cuda()
-        net.reserve(rows)
-        # the shader clock needs a few hundred milliseconds of load to settle: warm up for 0.4 s, time 0.4 s
-        t0 = time.perf_counter()
-        n1 = 0
-        while time.perf_counter() - t0 < 0.4:
-            net.forward(x)
-            torch.cuda.synchronize()
-            n1 += 1
-        n = max(5, n1)
-        t0 = time.perf_counter()
-        for _ in range(n):
-            net.forward(x)
-        torch.cuda.synchronize()
-        ms = (time.perf_counter() - t0) / n / nl * 1e3
-        fl = 2.0 * 9 * c * c * hw * hw * rows
-        print(f"{c:4d} ch {hw:2d}x{hw:<2d} rows={rows}: {ms * 1e3:8.1f} us/layer  {fl / ms / 1e9:6.1f} TFLOP/s "
-              f"({fl / ms / 1e9 / peak * 100:.1f}% of the {arith} ceiling)", flush=True)
-
-
-if __name__ == "__main__":
-    main()
+if os.environ.get("CSVAE_EXP_LIB"):
+    _lib.LIB_PATH = os.path.abspath(os.environ["CSVAE_EXP_LIB"])
+c = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+hw = int(sys.argv[2]) if len(sys.argv) > 2 else 28
+rows_list = [int(v) for v in sys.argv[3:]] or [125, 250, 500, 1000, 2000, 4000]
+g = torch.Generator().manual_seed(0)
+b = _lib.ProgramBuilder(c * hw * hw, c * hw * hw, 1)
+# two layers, so that the second finds its input's per-image maxima written by the first (the fp16 split's steady state)
+for i, (src, dst) in enumerate(((0, 1), (1, _lib.CS_NET_BUF_OUT))):
+    b.conv(src, dst, torch.randn(c, c, 3, 3, generator=g) / (3 * c ** 0.5), torch.randn(c, generator=g) * 0.1,
+           hin=hw, win=hw, relu=True)
+net = b.build()
+for rows in rows_list:
+    x = torch.randn(rows, c * hw * hw, generator=g).cuda()
+    net.reserve(rows)
+    for _ in range(3):
+        net.forward(x)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    n = 20
+    e0.record()
+    for _ in range(n):
+        net.forward(x)
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / n / 2
+    print(f"{c} channels {hw}x{hw}, {rows} images: {us:8.1f} us per layer, {us / rows:6.3f} us per image, "
+          f"{2 * 9 * c * c * hw * hw * rows / us / 1e6:7.1f} TFLOP/s")

@@ -534,6 +534,11 @@ int cs_debug_force_large_resample(int on);
 /* Test hook (no counterpart in the reference): 1 keeps the scalar log-weight kernel of the path for more than 64
  * proposals per example where its 16-byte-access form would run; both give the same bits. */
 int cs_debug_force_scalar_logw(int on);
+/* Test hook (no counterpart in the reference): a pass of a layer program over at least `min_rows` rows runs as two
+ * halves, the second on a stream of the handle's own beside the caller's (which waits for it before the call returns);
+ * 0 keeps every pass in the caller's stream.  Returns the previous value (default 8; a pass also needs about 40 GFLOP
+ * of work to be divided; a negative value divides every pass of at least -min_rows rows whatever its work). */
+int cs_debug_set_prog_two_streams(int min_rows);
 /* Test hook (no counterpart in the reference): matrix-kernel convolutions of launches that would leave half the CUs
  * without a workgroup run in small blocks (32 output channels each) when a block has at least `steps` (tap,
  * 32-channel chunk) steps; 0 keeps the large blocks for every launch.  Returns the previous value (default 18). */

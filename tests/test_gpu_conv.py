@@ -17,14 +17,17 @@ from tests.helpers import arith_fixture  # noqa: E402
 mlp_arith = arith_fixture()
 
 
-@pytest.fixture(autouse=True, params=["small_blocks_for_few_images", "large_blocks_always"])
+@pytest.fixture(autouse=True, params=["small_blocks_for_few_images", "large_blocks_always", "passes_in_two_halves"])
 def block_shapes(request):
     """Launches of a few images run in blocks of 32 output channels (so that they reach more CUs); every case here
-    runs with that rule and with the large blocks that full-size launches use."""
+    runs with that rule and with the large blocks that full-size launches use.  Passes with enough work run as two
+    halves on two streams: the third setting divides every pass of 8 rows and more that way."""
     from vae_conditional_sampling_amd import _lib
     prev = _lib.lib().cs_debug_set_small_launch_steps(18 if request.param.startswith("small") else 0)
+    prev2 = _lib.lib().cs_debug_set_prog_two_streams(-8 if request.param == "passes_in_two_halves" else 0)
     yield
     _lib.lib().cs_debug_set_small_launch_steps(prev)
+    _lib.lib().cs_debug_set_prog_two_streams(prev2)
 
 CONV_RTOL = 1e-5
 

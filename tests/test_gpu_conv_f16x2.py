@@ -16,13 +16,16 @@ pytestmark = pytest.mark.gpu
 RTOL = 1e-5   # of an image's largest output magnitude (float32-equivalent arithmetic, north-star tolerance)
 
 
-@pytest.fixture(autouse=True, params=["small_blocks_for_few_images", "large_blocks_always"])
+@pytest.fixture(autouse=True, params=["small_blocks_for_few_images", "large_blocks_always", "passes_in_two_halves"])
 def block_shapes(request):
     """Launches of a few images run in blocks of 32 output channels (so that they reach more CUs); every case here
-    runs with that rule and with the large blocks that full-size launches use."""
+    runs with that rule and with the large blocks that full-size launches use.  Passes with enough work run as two
+    halves on two streams: the third setting divides every pass of 8 rows and more that way."""
     prev = _lib.lib().cs_debug_set_small_launch_steps(18 if request.param.startswith("small") else 0)
+    prev2 = _lib.lib().cs_debug_set_prog_two_streams(-8 if request.param == "passes_in_two_halves" else 0)
     yield
     _lib.lib().cs_debug_set_small_launch_steps(prev)
+    _lib.lib().cs_debug_set_prog_two_streams(prev2)
 
 
 def _program(c_in, c_out, hw, n_layers, seed, upsample_last=False, residual=False):
@@ -113,3 +116,23 @@ def test_an_image_does_not_depend_on_the_rest_of_the_batch():
     assert torch.equal(yp, y[perm])
     ys = _forward(net, x[7:19], "f16x2")
     assert torch.equal(ys, y[7:19])
+
+
+def test_a_pass_in_two_halves_gives_the_bits_of_one_pass():
+    """Rows are independent: a pass divided over two streams must return exactly what the undivided pass returns
+    (odd row counts, a residual layer program, all three arithmetics)."""
+    net = _program(64, 64, 14, 4, seed=31, upsample_last=True, residual=True)
+    g = torch.Generator().manual_seed(8)
+    for rows in (9, 37, 130):
+        x = torch.randn(rows, 64 * 14 * 14, generator=g).cuda()
+        for arith in ("f16x2", "bf16x3", "f32"):
+            L = _lib.lib()
+            prev = L.cs_debug_set_prog_two_streams(0)
+            try:
+                one = _forward(net, x, arith)
+                L.cs_debug_set_prog_two_streams(-8)
+                two = _forward(net, x, arith)
+                again = _forward(net, x, arith)
+            finally:
+                L.cs_debug_set_prog_two_streams(prev)
+            assert torch.equal(one, two) and torch.equal(two, again), (rows, arith)

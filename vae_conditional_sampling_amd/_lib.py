@@ -207,6 +207,7 @@ def lib():
     L.cs_debug_force_scalar_logw.argtypes = [i32]
     L.cs_debug_set_narrow.argtypes = [i32]
     L.cs_debug_set_small_launch_steps.argtypes = [i32]
+    L.cs_debug_set_prog_two_streams.argtypes = [i32]
     L.cs_set_mlp_arith.argtypes = [i32]
     L.cs_mlp_set_arith.argtypes = [vp, i32]
     L.cs_mlp_get_arith.argtypes = [vp]

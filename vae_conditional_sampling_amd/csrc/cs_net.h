@@ -37,6 +37,9 @@ struct CsProgram {
   // per-image maxima of the activations (fp16 split): [layers + 1][ws_rows] words, slot i = output of layer i, the
   // last slot = the network input; zeroed at the start of every pass
   unsigned* amax_ws = nullptr;
+  // second stream of a pass that runs as two halves (cs_prog_launch), created on first use
+  hipStream_t side_stream[3] = {nullptr, nullptr, nullptr};
+  hipEvent_t side_fork = nullptr, side_join[3] = {nullptr, nullptr, nullptr};
   int in_dim = 0, out_dim = 0;
   int64_t buf_elems[CS_NET_NBUF] = {0};  // floats per network row of every buffer
   // workspace (scratch buffers 1..4, staged input, raw output), grown on demand

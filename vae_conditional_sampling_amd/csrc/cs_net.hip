@@ -20,6 +20,7 @@
 #include "cs_net.h"
 
 #include <cstring>
+#include <mutex>
 
 namespace {
 
@@ -2249,6 +2250,11 @@ void cs_prog_destroy(CsProgram* p) {
   if (p->d_blob3h) (void)hipFree(p->d_blob3h);
   if (p->amax_ws) (void)hipFree(p->amax_ws);
   if (p->ws) (void)hipFree(p->ws);
+  for (int k = 0; k < 3; ++k) {
+    if (p->side_stream[k]) (void)hipStreamDestroy(p->side_stream[k]);
+    if (p->side_join[k]) (void)hipEventDestroy(p->side_join[k]);
+  }
+  if (p->side_fork) (void)hipEventDestroy(p->side_fork);
   delete p;
 }
 
@@ -2493,6 +2499,27 @@ extern "C" int cs_net_reserve(cs_mlp_t* net, int64_t rows) {
   return prog_grow_workspace(net->prog, chunk, per_row);
 }
 
+// A pass of at least this many rows (and enough work, see cs_prog_launch) runs as two halves on two streams (0: never).
+int g_prog_two_streams = getenv("CSVAE_PROG_TWO_STREAMS") ? atoi(getenv("CSVAE_PROG_TWO_STREAMS")) : 8;
+// streams and events of a pass that runs in parts (per network handle: calls on one handle may not overlap anyway,
+// its workspace is one); false when they cannot be created
+static bool prog_side(CsProgram* p, int nside) {
+  if (!p->side_fork && hipEventCreateWithFlags(&p->side_fork, hipEventDisableTiming) != hipSuccess) return false;
+  for (int k = 0; k < nside; ++k) {
+    if (p->side_stream[k]) continue;
+    if (hipStreamCreateWithFlags(&p->side_stream[k], hipStreamNonBlocking) != hipSuccess) { p->side_stream[k] = nullptr; return false; }
+    if (hipEventCreateWithFlags(&p->side_join[k], hipEventDisableTiming) != hipSuccess) return false;
+  }
+  return true;
+}
+int g_prog_parts = getenv("CSVAE_PROG_PARTS") ? atoi(getenv("CSVAE_PROG_PARTS")) : 2;   // (measurement switch, 2..4)
+
+extern "C" int cs_debug_set_prog_two_streams(int min_rows) {
+  const int prev = g_prog_two_streams;
+  g_prog_two_streams = min_rows;
+  return prev;
+}
+
 int cs_prog_launch(const CsMlpArgs& a, hipStream_t stream) {
   CsProgram* p = (CsProgram*)a.net.prog;
   int dev = 0;
@@ -2517,80 +2544,136 @@ int cs_prog_launch(const CsMlpArgs& a, hipStream_t stream) {
   }
   const int64_t chunk = prog_chunk_rows(p, a.rows, &per_row);
   if (int rc = prog_grow_workspace(p, chunk, per_row)) return rc;
+  // fp16 split: slot i of the table of per-image maxima belongs to the output of layer i (written by the halo
+  // kernel's epilogue), the last slot to the network input; a source whose producer did not write its slot gets a
+  // reduction pass of its own
+  const size_t nlay = p->layers.size();
+  bool any_half = false;
+  std::vector<char> wants(nlay, 0);  // a later fp16-split layer reads this layer's output
+  for (const CsLayer& L : p->layers)
+    if (layer_half_kind(*p, L) != 0) {
+      any_half = true;
+      if (L.src_layer >= 0) wants[(size_t)L.src_layer] = 1;
+    }
   for (int64_t row0 = 0; row0 < a.rows; row0 += chunk) {
     const int64_t rows = a.rows - row0 < chunk ? a.rows - row0 : chunk;
-    float* buf[CS_NET_NBUF];
-    for (int b = 0; b < CS_NET_NBUF; ++b) buf[b] = p->ws + prefix[b] * chunk;
-    const float* input;
-    if (a.mode == CS_MLP_DEC && a.in == nullptr) {
-      if (int rc = cs_dec_stage_launch(a, row0, rows, stream)) return rc;
-      input = a.Z + row0 * a.Zd;
-    } else if (a.in_off == nullptr && a.in_stride == p->in_dim && !a.in_u8) {
-      input = a.in + row0 * p->in_dim;
-    } else {
-      hipLaunchKernelGGL(cs_gather_rows_kernel, dim3(blocks_for(rows * p->in_dim)), dim3(256), 0, stream, a.in,
-                         a.in_stride, a.in_off, row0, rows, p->in_dim, buf[CS_NET_BUF_IN], a.in_u8);
-      input = buf[CS_NET_BUF_IN];
-    }
-    float* raw = a.mode == CS_MLP_RAW ? a.out + row0 * p->out_dim : buf[CS_NET_BUF_OUT];
-    // fp16 split: slot i of the table of per-image maxima belongs to the output of layer i (written by the halo
-    // kernel's epilogue), the last slot to the network input; a source whose producer did not write its slot gets a
-    // reduction pass of its own
-    const size_t nlay = p->layers.size();
-    std::vector<char> have(nlay + 1, 0);
-    bool any_half = false;
-    std::vector<char> wants(nlay, 0);  // a later fp16-split layer reads this layer's output
+    // Rows are independent, and every launch of a layer pays a ramp and a drain of about two workgroup lifetimes
+    // (60 - 80 us for the halo kernels, whatever the number of images) during which most CUs wait.  A pass of enough
+    // rows therefore runs as two halves, the second on a stream of the library's own: while one half's layer
+    // drains, the other half's workgroups take the CUs.  Each half has its own part of every workspace buffer and
+    // of the maxima table; the caller's stream waits for the second half before the call returns.
+    int nh = 1;
+    // (it pays from about 40 GFLOP per pass: below that the layers' launches themselves are the time, and a split
+    // doubles them -- MNIST-GMM nets at 256 images 4 % slower, Omniglot nets at 64 images 4 - 10 % faster)
+    double pass_flops = 0.0;
     for (const CsLayer& L : p->layers)
-      if (layer_half_kind(*p, L) != 0) {
-        any_half = true;
-        if (L.src_layer >= 0) wants[(size_t)L.src_layer] = 1;
-      }
+      if (L.d.op == CS_OP_CONV || L.d.op == CS_OP_LINEAR)
+        pass_flops += 2.0 * L.d.ksize * L.d.ksize * L.d.cin * L.d.cout * L.d.hout * L.d.wout * (double)rows;
+    // (a negative setting divides every pass of at least that many rows: tests)
+    if ((g_prog_two_streams > 0 && rows >= g_prog_two_streams && nlay >= 4 && pass_flops >= 4.0e10) ||
+        (g_prog_two_streams < 0 && rows >= -g_prog_two_streams)) {
+      nh = g_prog_parts < 2 ? 2 : g_prog_parts > 4 ? 4 : g_prog_parts;
+      if (!prog_side(p, nh - 1)) nh = 1;
+    }
+    const bool side = nh > 1;
+    struct Half {
+      int64_t row_begin, rows, ws_off;
+      hipStream_t stream;
+      float* buf[CS_NET_NBUF];
+      const float* input;
+      float* raw;
+      std::vector<char> have;
+    } h[4];
+    const int64_t part = side ? (((rows + nh - 1) / nh + 3) & ~(int64_t)3) : rows;
+    for (int k = 0; k < nh; ++k) {
+      h[k].ws_off = k * part;
+      h[k].row_begin = row0 + h[k].ws_off;
+      h[k].rows = std::min<int64_t>(part, rows - h[k].ws_off);
+      h[k].stream = k ? p->side_stream[k - 1] : stream;
+      for (int b = 0; b < CS_NET_NBUF; ++b)
+        h[k].buf[b] = p->ws + prefix[b] * chunk + h[k].ws_off * ((p->buf_elems[b] + 3) & ~(int64_t)3);
+      h[k].have.assign(nlay + 1, 0);
+    }
+    while (nh > 1 && h[nh - 1].rows <= 0) --nh;
     if (any_half) CS_HIP(hipMemsetAsync(p->amax_ws, 0, (nlay + 1) * (size_t)p->ws_rows * sizeof(unsigned), stream));
-    for (size_t li = 0; li < nlay; ++li) {
+    if (side) {
+      CS_HIP(hipEventRecord(p->side_fork, stream));
+      for (int k = 1; k < nh; ++k) CS_HIP(hipStreamWaitEvent(h[k].stream, p->side_fork, 0));
+    }
+    int rc_all = CS_OK;
+    for (int k = 0; k < nh && rc_all == CS_OK; ++k) {
+      Half& H = h[k];
+      if (a.mode == CS_MLP_DEC && a.in == nullptr) {
+        rc_all = cs_dec_stage_launch(a, H.row_begin, H.rows, H.stream);
+        H.input = a.Z + H.row_begin * a.Zd;
+      } else if (a.in_off == nullptr && a.in_stride == p->in_dim && !a.in_u8) {
+        H.input = a.in + H.row_begin * p->in_dim;
+      } else {
+        hipLaunchKernelGGL(cs_gather_rows_kernel, dim3(blocks_for(H.rows * p->in_dim)), dim3(256), 0, H.stream, a.in,
+                           a.in_stride, a.in_off, H.row_begin, H.rows, p->in_dim, H.buf[CS_NET_BUF_IN], a.in_u8);
+        H.input = H.buf[CS_NET_BUF_IN];
+      }
+      H.raw = a.mode == CS_MLP_RAW ? a.out + H.row_begin * p->out_dim : H.buf[CS_NET_BUF_OUT];
+    }
+    for (size_t li = 0; li < nlay && rc_all == CS_OK; ++li) {
       const CsLayer& L = p->layers[li];
       const cs_layer_desc& d = L.d;
-      const float* src = d.src == CS_NET_BUF_IN ? input : buf[d.src];
-      const float* res = d.res < 0 ? nullptr : (d.res == CS_NET_BUF_IN ? input : buf[d.res]);
-      float* dst = d.dst == CS_NET_BUF_OUT ? raw : buf[d.dst];
-      if (d.op == CS_OP_CONV || d.op == CS_OP_LINEAR) {
-        const unsigned* in_amax = nullptr;
-        unsigned* out_amax = nullptr;
-        const int kind = any_half ? layer_half_kind(*p, L) : 0;
-        if (kind != 0) {
-          const size_t slot = L.src_layer < 0 ? nlay : (size_t)L.src_layer;
-          unsigned* tab = p->amax_ws + slot * (size_t)p->ws_rows;
-          if (!have[slot]) {
-            const int64_t elems = (int64_t)d.cin * d.hin * d.win;
-            const unsigned gx = (unsigned)std::min<int64_t>((elems / 4 + 255) / 256 > 0 ? (elems / 4 + 255) / 256 : 1, 16);
-            hipLaunchKernelGGL(cs_image_amax_kernel, dim3(gx, (unsigned)std::min<int64_t>(rows, 32768)), dim3(256), 0, stream, src,
-                               elems, rows, tab);
-            have[slot] = 1;
+      for (int k = 0; k < nh && rc_all == CS_OK; ++k) {
+        Half& H = h[k];
+        const int64_t hrows = H.rows;
+        hipStream_t hs = H.stream;
+        const float* src = d.src == CS_NET_BUF_IN ? H.input : H.buf[d.src];
+        const float* res = d.res < 0 ? nullptr : (d.res == CS_NET_BUF_IN ? H.input : H.buf[d.res]);
+        float* dst = d.dst == CS_NET_BUF_OUT ? H.raw : H.buf[d.dst];
+        if (d.op == CS_OP_CONV || d.op == CS_OP_LINEAR) {
+          const unsigned* in_amax = nullptr;
+          unsigned* out_amax = nullptr;
+          const int kind = any_half ? layer_half_kind(*p, L) : 0;
+          if (kind != 0) {
+            const size_t slot = L.src_layer < 0 ? nlay : (size_t)L.src_layer;
+            unsigned* tab = p->amax_ws + slot * (size_t)p->ws_rows + H.ws_off;
+            if (!H.have[slot]) {
+              const int64_t elems = (int64_t)d.cin * d.hin * d.win;
+              const unsigned gx = (unsigned)std::min<int64_t>((elems / 4 + 255) / 256 > 0 ? (elems / 4 + 255) / 256 : 1, 16);
+              hipLaunchKernelGGL(cs_image_amax_kernel, dim3(gx, (unsigned)std::min<int64_t>(hrows, 32768)), dim3(256), 0, hs,
+                                 src, elems, hrows, tab);
+              H.have[slot] = 1;
+            }
+            in_amax = tab;
           }
-          in_amax = tab;
+          if (any_half && wants[li]) out_amax = p->amax_ws + li * (size_t)p->ws_rows + H.ws_off;
+          bool wrote = false;
+          rc_all = launch_conv(*p, L, src, res, dst, hrows, hs, in_amax, out_amax, &wrote);
+          if (wrote) H.have[li] = 1;
+        } else if (d.op == CS_OP_LAYERNORM) {
+          hipLaunchKernelGGL(cs_layernorm_kernel, dim3((unsigned)((hrows + 3) / 4)), dim3(256), 0, hs, src, dst, hrows,
+                             d.cin, p->d_blob + d.w_off, p->d_blob + d.b_off, d.relu);
+        } else if (d.op == CS_OP_AVGPOOL) {
+          hipLaunchKernelGGL(cs_avgpool_kernel, dim3(blocks_for(hrows * d.cin)), dim3(256), 0, hs, src, dst, hrows,
+                             d.hin * d.win, d.cin);
+        } else {
+          unsigned* oam = (any_half && wants[li] && g_conv_fused_amax) ? p->amax_ws + li * (size_t)p->ws_rows + H.ws_off : nullptr;
+          const int per = d.hout * d.wout * d.cin;
+          const unsigned gx = (unsigned)std::max(1, std::min(8, (per + 2047) / 2048));  // 8+ elements per thread
+          hipLaunchKernelGGL(cs_resize_kernel, dim3(gx, (unsigned)std::min<int64_t>(hrows, 32768)), dim3(256), 0, hs,
+                             src, dst, hrows, d.hin, d.win, d.hout, d.wout, d.cin, oam);
+          if (oam) H.have[li] = 1;
         }
-        if (any_half && wants[li]) out_amax = p->amax_ws + li * (size_t)p->ws_rows;
-        bool wrote = false;
-        if (int rc = launch_conv(*p, L, src, res, dst, rows, stream, in_amax, out_amax, &wrote)) return rc;
-        if (wrote) have[li] = 1;
-      } else if (d.op == CS_OP_LAYERNORM) {
-        hipLaunchKernelGGL(cs_layernorm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, src, dst, rows,
-                           d.cin, p->d_blob + d.w_off, p->d_blob + d.b_off, d.relu);
-      } else if (d.op == CS_OP_AVGPOOL) {
-        hipLaunchKernelGGL(cs_avgpool_kernel, dim3(blocks_for(rows * d.cin)), dim3(256), 0, stream, src, dst, rows,
-                           d.hin * d.win, d.cin);
-      } else {
-        unsigned* oam = (any_half && wants[li] && g_conv_fused_amax) ? p->amax_ws + li * (size_t)p->ws_rows : nullptr;
-        const int per = d.hout * d.wout * d.cin;
-        const unsigned gx = (unsigned)std::max(1, std::min(8, (per + 2047) / 2048));  // 8+ elements per thread
-        hipLaunchKernelGGL(cs_resize_kernel, dim3(gx, (unsigned)std::min<int64_t>(rows, 32768)), dim3(256), 0, stream,
-                           src, dst, rows, d.hin, d.win, d.hout, d.wout, d.cin, oam);
-        if (oam) have[li] = 1;
       }
     }
-    if (a.mode == CS_MLP_ENC)
-      hipLaunchKernelGGL(cs_enc_finish_kernel, dim3(blocks_for(rows * a.Zd)), dim3(256), 0, stream, a, raw, row0, rows);
-    else if (a.mode == CS_MLP_DEC)
-      hipLaunchKernelGGL(cs_dec_finish_kernel, dim3((unsigned)rows), dim3(64), 0, stream, a, raw, row0);
+    for (int k = 0; k < nh && rc_all == CS_OK; ++k) {
+      Half& H = h[k];
+      if (a.mode == CS_MLP_ENC)
+        hipLaunchKernelGGL(cs_enc_finish_kernel, dim3(blocks_for(H.rows * a.Zd)), dim3(256), 0, H.stream, a, H.raw,
+                           H.row_begin, H.rows);
+      else if (a.mode == CS_MLP_DEC)
+        hipLaunchKernelGGL(cs_dec_finish_kernel, dim3((unsigned)H.rows), dim3(64), 0, H.stream, a, H.raw, H.row_begin);
+    }
+    for (int k = 1; k < nh; ++k) {  // also on an error: nothing of the other streams may outlive the call unobserved
+      (void)hipEventRecord(p->side_join[k - 1], h[k].stream);
+      (void)hipStreamWaitEvent(stream, p->side_join[k - 1], 0);
+    }
+    if (rc_all != CS_OK) return rc_all;
     CS_HIP(hipGetLastError());
   }
   return CS_OK;

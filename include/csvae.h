@@ -412,6 +412,17 @@ int cs_imputation_errors(const float* X, const float* X_true, const uint8_t* M, 
 int cs_latent_wasserstein(const float* q_imp, const float* q_true, int64_t B, int32_t K, int32_t Zd, float* out,
                           void* stream);
 
+/* Order statistics of the rows of x[rows, m] (device, float32): out[row, j] = the ranks[j]-th smallest value of the
+ * row (0-based; `ranks` is a HOST array of nq <= 16 ranks common to all rows; rows <= 65535 per call).  Radix selection
+ * in three passes over the data: the per-iteration quantiles of the point-wise diagnostics over a whole test set
+ * (np.quantile in test_epoch_end, test_step_vae_sampling.py:824-858) without sorting it.  The value returned is an
+ * element of the row; NaNs order above +inf (below -inf with the sign bit set), a caller that must answer NaN for a
+ * row holding one checks for it itself.  `workspace`: cs_row_order_statistics_workspace(rows, nq) bytes of device
+ * memory. */
+int64_t cs_row_order_statistics_workspace(int64_t rows, int32_t nq);
+int cs_row_order_statistics(const float* x, int64_t rows, int64_t m, const int64_t* ranks, int32_t nq, float* out,
+                            void* workspace, int64_t workspace_bytes, void* stream);
+
 /* HOST function (no device work, callable from any thread): one piece of a raw deflate stream (RFC 1951) for
  * src[0..n), for the `.npz` artefacts the samplers write with np.savez_compressed (test_step_vae_sampling.py:785-791,
  * 2039-2045).  Matches are looked for at distance `stride` only (the row length in bytes of a [.., K, D] array,

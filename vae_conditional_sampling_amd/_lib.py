@@ -212,6 +212,9 @@ def lib():
     L.cs_mlp_set_arith.argtypes = [vp, i32]
     L.cs_mlp_get_arith.argtypes = [vp]
     L.cs_net_reserve.argtypes = [vp, i64]
+    L.cs_row_order_statistics_workspace.restype = i64
+    L.cs_row_order_statistics_workspace.argtypes = [i64, i32]
+    L.cs_row_order_statistics.argtypes = [vp, i64, i64, C.POINTER(i64), i32, vp, vp, i64, vp]
     L.cs_crc32.restype = u32
     L.cs_crc32.argtypes = [vp, i64, u32]
     L.cs_crc32_combine.restype = u32

@@ -78,6 +78,21 @@ def imputation_latent_wass(X_imp, X_true, vae, *, q_true=None, out=None):
     return out
 
 
+def _order_statistics(x, ranks):
+    """out[row, j] = the ranks[j]-th smallest value of row `row` of the device matrix x (cs_row_order_statistics)."""
+    rows, m = x.shape
+    L = _lib.lib()
+    nq = len(ranks)
+    out = torch.empty(rows, nq, device=x.device, dtype=torch.float32)
+    x = x.contiguous()
+    for r0 in range(0, rows, 65535):
+        r1 = min(rows, r0 + 65535)
+        ws = torch.empty(L.cs_row_order_statistics_workspace(r1 - r0, nq), dtype=torch.uint8, device=x.device)
+        _lib.check(L.cs_row_order_statistics(_lib.ptr(x[r0:r1]), r1 - r0, m, (C.c_int64 * nq)(*[int(r) for r in ranks]), nq,
+                                             _lib.ptr(out[r0:r1]), _lib.ptr(ws), ws.numel(), _lib.current_stream()))
+    return out
+
+
 def pointwise_summary(values, quantiles, device=None):
     """Per-iteration summary of a point-wise metric over the whole test set (the aggregation of
     irwg/sampling/test_step_vae_sampling.py:824-858): ``values`` is the list of per-batch series ``[t, n_b, k]``
@@ -111,13 +126,21 @@ def pointwise_summary(values, quantiles, device=None):
         mean[t0:t1] = over_data.mean(dim=1).cpu().numpy()
         std[t0:t1] = (over_data.std(dim=1, unbiased=True) if K != 1 else torch.ones(t1 - t0, device=dev)).cpu().numpy()
         if len(quantiles):
-            srt = x.reshape(t1 - t0, m).sort(dim=1).values
-            a, b = srt[:, lo], srt[:, hi]           # [tc, q]
+            flat = x.reshape(t1 - t0, m)
+            if flat.is_cuda and 2 * len(quantiles) <= 16:
+                # the two neighbours of every quantile by radix selection (cs_row_order_statistics): three reads of
+                # the values instead of a sort
+                ab = _order_statistics(flat, torch.cat([lo, hi]).tolist())
+                a, b = ab[:, :len(quantiles)], ab[:, len(quantiles):]
+                has_nan = flat.isnan().any(dim=1, keepdim=True)
+            else:
+                srt = flat.sort(dim=1).values
+                a, b = srt[:, lo], srt[:, hi]       # [tc, q]
+                has_nan = srt[:, -1:].isnan()       # the sort puts NaNs last
             d = b - a
             # numpy's _lerp: a + d g, taken from the other end when g >= 0.5
             r = torch.where(g >= 0.5, b - d * (1 - g), a + d * g)
-            # np.quantile returns NaN for an iteration that holds a NaN (test_step_vae_sampling.py:847); the sort
-            # puts NaNs last, so the last entry tells
-            r = torch.where(srt[:, -1:].isnan(), torch.full_like(r, float("nan")), r)
+            # np.quantile returns NaN for an iteration that holds a NaN (test_step_vae_sampling.py:847)
+            r = torch.where(has_nan, torch.full_like(r, float("nan")), r)
             quant[:, t0:t1] = r.t().cpu().numpy()
     return mean, std, quant

@@ -15,6 +15,7 @@ namespace {
 
 constexpr int SEL_MAXQ = 16;     // order statistics per row
 constexpr int SEL_BINS = 2048;   // 11 bits per pass (the last pass: 10)
+constexpr int SEL_GROUP = 4;     // histograms a workgroup keeps in LDS at a time
 
 __device__ __forceinline__ uint32_t sel_key(float v) {
   const uint32_t u = __float_as_uint(v);
@@ -47,7 +48,7 @@ __global__ void __launch_bounds__(256) cs_select_init_kernel(SelState* st, const
 // counts[row][slot j][digit] += ...   for the slice of the row this block owns
 __global__ void __launch_bounds__(256) cs_select_count_kernel(const float* x, int64_t m, const SelState* st, int nq, int pass,
                                                               uint32_t* counts) {
-  extern __shared__ uint32_t lh[];   // [nq][SEL_BINS] (only the rows of distinct prefixes are used; pass 0: one)
+  extern __shared__ uint32_t lh[];   // [SEL_GROUP][SEL_BINS]
   __shared__ uint32_t s_pf[SEL_MAXQ];
   __shared__ int s_own[SEL_MAXQ];
   __shared__ int s_ns;
@@ -62,31 +63,36 @@ __global__ void __launch_bounds__(256) cs_select_count_kernel(const float* x, in
   }
   __syncthreads();
   const int ns = s_ns;
-  for (int i = threadIdx.x; i < ns * SEL_BINS; i += 256) lh[s_own[i / SEL_BINS] * SEL_BINS + (i % SEL_BINS)] = 0;
-  __syncthreads();
   const int64_t per = (m + gridDim.x - 1) / gridDim.x;
   const int64_t lo = (int64_t)blockIdx.x * per, hi = lo + per < m ? lo + per : m;
   const float* xr = x + row * m;
   const int pshift = shift + sel_bits(pass);   // bits below the prefix (pass 0: no prefix)
-  auto count = [&](float v) {
-    const uint32_t k = sel_key(v);
-    const uint32_t kp = pass == 0 ? 0u : (k >> pshift);
-    const uint32_t dg = (k >> shift) & (uint32_t)(nb - 1);
-    for (int t = 0; t < ns; ++t)
-      if (kp == s_pf[t]) { atomicAdd(&lh[s_own[t] * SEL_BINS + dg], 1u); break; }
-  };
-  int64_t i = lo + threadIdx.x;
-  for (; i + 768 < hi; i += 1024) {   // four loads in flight per thread
-    const float v0 = xr[i], v1 = xr[i + 256], v2 = xr[i + 512], v3 = xr[i + 768];
-    count(v0); count(v1); count(v2); count(v3);
-  }
-  for (; i < hi; i += 256) count(xr[i]);
-  __syncthreads();
   uint32_t* cr = counts + row * (int64_t)nq * SEL_BINS;
-  for (int t = threadIdx.x; t < ns * SEL_BINS; t += 256) {
-    const int o = s_own[t / SEL_BINS] * SEL_BINS + (t % SEL_BINS);
-    const uint32_t c = lh[o];
-    if (c) atomicAdd(&cr[o], c);
+  // SEL_GROUP histograms at a time (32 KB of LDS: several workgroups per CU to hide the loads behind); a row with more
+  // distinct prefixes reads its slice once per group
+  for (int g0 = 0; g0 < ns; g0 += SEL_GROUP) {
+    const int gn = ns - g0 < SEL_GROUP ? ns - g0 : SEL_GROUP;
+    for (int i = threadIdx.x; i < gn * SEL_BINS; i += 256) lh[i] = 0;
+    __syncthreads();
+    auto count = [&](float v) {
+      const uint32_t k = sel_key(v);
+      const uint32_t kp = pass == 0 ? 0u : (k >> pshift);
+      const uint32_t dg = (k >> shift) & (uint32_t)(nb - 1);
+      for (int t = 0; t < gn; ++t)
+        if (kp == s_pf[g0 + t]) { atomicAdd(&lh[t * SEL_BINS + dg], 1u); break; }
+    };
+    int64_t i = lo + threadIdx.x;
+    for (; i + 768 < hi; i += 1024) {   // four loads in flight per thread
+      const float v0 = xr[i], v1 = xr[i + 256], v2 = xr[i + 512], v3 = xr[i + 768];
+      count(v0); count(v1); count(v2); count(v3);
+    }
+    for (; i < hi; i += 256) count(xr[i]);
+    __syncthreads();
+    for (int t = threadIdx.x; t < gn * SEL_BINS; t += 256) {
+      const uint32_t c = lh[t];
+      if (c) atomicAdd(&cr[s_own[g0 + t / SEL_BINS] * SEL_BINS + (t % SEL_BINS)], c);
+    }
+    __syncthreads();
   }
 }
 
@@ -183,19 +189,10 @@ extern "C" int cs_row_order_statistics(const float* x, int64_t rows, int64_t m, 
   if (bpr > want && want >= 1) bpr = bpr < 4 * want ? bpr : 4 * want;
   if (bpr < 1) bpr = 1;
   if (bpr > 65535) bpr = 65535;
-  const size_t lds = (size_t)nq * SEL_BINS * 4;
-  static bool attr_set[64] = {};
-  int dev = 0;
-  CS_HIP(hipGetDevice(&dev));
-  if (dev >= 0 && dev < 64 && !attr_set[dev]) {
-    CS_HIP(hipFuncSetAttribute((const void*)cs_select_count_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                               SEL_MAXQ * SEL_BINS * 4));
-    attr_set[dev] = true;
-  }
+  const size_t lds = (size_t)SEL_GROUP * SEL_BINS * 4;
   for (int pass = 0; pass < 3; ++pass) {
-    // (pass 0 has one prefix, the empty one, kept by target 0: one histogram of LDS, more blocks per CU)
-    hipLaunchKernelGGL(cs_select_count_kernel, dim3((unsigned)bpr, (unsigned)rows), dim3(256), pass == 0 ? SEL_BINS * 4 : lds, st,
-                       x, m, state, nq, pass, counts);
+    hipLaunchKernelGGL(cs_select_count_kernel, dim3((unsigned)bpr, (unsigned)rows), dim3(256), lds, st, x, m, state, nq, pass,
+                       counts);
     hipLaunchKernelGGL(cs_select_step_kernel, dim3((unsigned)rows), dim3(64), 0, st, state, nq, pass, counts, out);
   }
   CS_HIP(hipGetLastError());

@@ -195,6 +195,9 @@ int CsObserver::iteration(int32_t t, const float* X, const uint8_t* M, hipStream
     float* kept = o->X_store + (int64_t)t * chains * D;
     CS_HIP(hipMemcpyAsync(kept, X, (size_t)chains * D * sizeof(float), hipMemcpyDeviceToDevice, stream));
     if (side) {
+      // (the events are the device's, shared by all callers: a wait refers to the record made just before it only
+      // if no other thread records in between)
+      std::lock_guard<std::mutex> lock(g_side_mutex);
       CS_HIP(hipEventRecord(copied, stream));
       CS_HIP(hipStreamWaitEvent(side, copied, 0));
       Xd = kept;
@@ -222,6 +225,7 @@ int CsObserver::iteration(int32_t t, const float* X, const uint8_t* M, hipStream
 
 int CsObserver::finish(hipStream_t stream) {
   if (!side) return CS_OK;
+  std::lock_guard<std::mutex> lock(g_side_mutex);
   CS_HIP(hipEventRecord(done, side));
   CS_HIP(hipStreamWaitEvent(stream, done, 0));
   return CS_OK;

@@ -11,6 +11,7 @@ struct CsResampleArgs {
   int Kp, S, G, c;       // resampling groups: G groups, c draws each
   int mixG, mixc;        // mixture groups (dmis: 1,K'; within groups: G,c; smis: K',1)
   int Kimp;              // chains that are imputed (<= K: historical proposals are not)
+  float* x_copy;         // optional [B,Kimp,D]: the new imputations are also written here (a run that keeps them)
   int NS;                // output slots of the resampling = G*c (K', or glr_pad_to when padded)
   int lds_per_wave;      // floats
   int E;                 // examples per wavefront
@@ -121,12 +122,17 @@ __device__ __forceinline__ void cs_lair_impute_item(const CsResampleArgs& a, int
       if (clip && !(fabsf(xn[r]) < INFINITY)) xn[r] = xo[r];
     }
   }
+  float* xc = a.x_copy ? a.x_copy + (be * Kimp + n) * D : nullptr;
   if (full) {
     *(f32x4_u*)(xw + 4 * dq) = xn;
+    if (xc) *(f32x4_u*)(xc + 4 * dq) = xn;
   } else {
 #pragma unroll
     for (int r = 0; r < 4; ++r)
-      if (4 * dq + r < D) xw[4 * dq + r] = xn[r];
+      if (4 * dq + r < D) {
+        xw[4 * dq + r] = xn[r];
+        if (xc) xc[4 * dq + r] = xn[r];
+      }
   }
 }
 #endif

@@ -656,7 +656,12 @@ extern "C" int cs_lair_decode(const cs_mlp_t* dec, const cs_lair_cfg* c, const c
   return cs_mlp_launch(a, (hipStream_t)stream);
 }
 
+static int lair_resample_impute(const cs_lair_cfg* c, const cs_lair_bufs* b, const cs_rng* rng, float* x_copy, void* stream);
 extern "C" int cs_lair_resample_impute(const cs_lair_cfg* c, const cs_lair_bufs* b, const cs_rng* rng, void* stream) {
+  return lair_resample_impute(c, b, rng, nullptr, stream);
+}
+// x_copy: optional [B,K_impute,D], receives the new imputations beside X (a run that keeps every iteration's)
+static int lair_resample_impute(const cs_lair_cfg* c, const cs_lair_bufs* b, const cs_rng* rng, float* x_copy, void* stream) {
   if (int rc = check_cfg(c, b)) return rc;
   if (c->B == 0) return CS_OK;  // empty batch: nothing to do (its tensors have no storage)
   CS_REQUIRE(b->X && b->M && b->q && b->Z && b->gen && b->gen_ll && b->log_w && b->norm_log_w && b->idx &&
@@ -667,6 +672,7 @@ extern "C" int cs_lair_resample_impute(const cs_lair_cfg* c, const cs_lair_bufs*
   a.cfg = *c;
   a.b = *b;
   a.rng = cs_make_philox(rng);
+  a.x_copy = x_copy;
   a.Kp = c->K + c->R;
   a.S = c->I * a.Kp;
   a.Kimp = c->K_impute > 0 ? c->K_impute : c->K;
@@ -741,11 +747,15 @@ extern "C" int cs_lair_resample_impute(const cs_lair_cfg* c, const cs_lair_bufs*
   return CS_OK;
 }
 
-extern "C" int cs_lair_step(const cs_mlp_t* enc, const cs_mlp_t* dec, const cs_lair_cfg* c, const cs_lair_bufs* b,
-                            const cs_rng* rng, void* stream) {
+static int lair_step(const cs_mlp_t* enc, const cs_mlp_t* dec, const cs_lair_cfg* c, const cs_lair_bufs* b, const cs_rng* rng,
+                     float* x_copy, void* stream) {
   if (int rc = cs_lair_encode(enc, c, b, stream)) return rc;
   if (int rc = cs_lair_decode(dec, c, b, rng, stream)) return rc;
-  return cs_lair_resample_impute(c, b, rng, stream);
+  return lair_resample_impute(c, b, rng, x_copy, stream);
+}
+extern "C" int cs_lair_step(const cs_mlp_t* enc, const cs_mlp_t* dec, const cs_lair_cfg* c, const cs_lair_bufs* b,
+                            const cs_rng* rng, void* stream) {
+  return lair_step(enc, dec, c, b, rng, nullptr, stream);
 }
 
 // ----------------------------------------------------------------------------------------
@@ -892,8 +902,10 @@ extern "C" int cs_lair_run_observed(const cs_mlp_t* enc, const cs_mlp_t* dec, co
     }
     cs_rng rt = r;
     rt.iteration = r.iteration + (uint32_t)t;
-    int rc = cs_lair_step(enc, dec, c, &b, &rt, stream);
-    if (rc == CS_OK) rc = observer.iteration(t, b.X, b.M, (hipStream_t)stream);
+    // (the imputation kernel writes the kept copy itself: no copy launch in the chain)
+    float* kept = obs && obs->X_store ? obs->X_store + (int64_t)t * B * c->K * c->D : nullptr;
+    int rc = lair_step(enc, dec, c, &b, &rt, kept, stream);
+    if (rc == CS_OK) rc = observer.iteration(t, b.X, b.M, (hipStream_t)stream, kept != nullptr);
     if (rc != CS_OK) {
       (void)observer.finish((hipStream_t)stream);
       return rc;

@@ -186,14 +186,15 @@ int CsObserver::begin(const cs_mlp_t* enc_, const cs_run_observe* o_, int64_t B_
   return CS_OK;
 }
 
-int CsObserver::iteration(int32_t t, const float* X, const uint8_t* M, hipStream_t stream) {
+int CsObserver::iteration(int32_t t, const float* X, const uint8_t* M, hipStream_t stream, bool already_kept) {
   if (!o || B == 0) return CS_OK;
   const int64_t chains = B * K;
   const float* Xd = X;            // what the diagnostics read
   hipStream_t ds = stream;        // and where
   if (o->X_store) {
     float* kept = o->X_store + (int64_t)t * chains * D;
-    CS_HIP(hipMemcpyAsync(kept, X, (size_t)chains * D * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    if (!already_kept)
+      CS_HIP(hipMemcpyAsync(kept, X, (size_t)chains * D * sizeof(float), hipMemcpyDeviceToDevice, stream));
     if (side) {
       // (the events are the device's, shared by all callers: a wait refers to the record made just before it only
       // if no other thread records in between)

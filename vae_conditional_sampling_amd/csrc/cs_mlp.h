@@ -93,7 +93,8 @@ struct CsObserver {
   hipStream_t side = nullptr;     // null: everything in the run's stream
   hipEvent_t copied = nullptr, done = nullptr;
   int begin(const cs_mlp_t* enc, const cs_run_observe* o, int64_t B, int32_t K, int32_t D, int32_t Zd, int32_t latent_dist);
-  int iteration(int32_t t, const float* X, const uint8_t* M, hipStream_t stream);
+  // kept: X_store[t] already holds X (written by the iteration's own kernel)
+  int iteration(int32_t t, const float* X, const uint8_t* M, hipStream_t stream, bool kept = false);
   int finish(hipStream_t stream);
 };
 // CS_ARITH_* in force for fused-MLP launches (cs_set_mlp_arith, or CSVAE_MLP_ARITH at first use)

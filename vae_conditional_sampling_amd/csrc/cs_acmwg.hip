@@ -25,6 +25,7 @@ struct CsAcmwgArgs {
   cs_acmwg_cfg cfg;
   cs_acmwg_bufs b;
   CsPhilox rng;
+  float* x_copy;   // optional [B,K,D]: the accept kernel writes the new imputations here too (a run that keeps them)
 };
 
 __device__ __forceinline__ float wsum(float v) {
@@ -198,6 +199,7 @@ __global__ void __launch_bounds__(256) cs_acmwg_accept_kernel(const CsAcmwgArgs 
   float* go = a.b.gen_old + tc * P;
   const float* gn = a.b.gen_new + tc * P;
   float* Xr = a.b.X + tc * D;
+  float* Xc = a.x_copy ? a.x_copy + tc * D : nullptr;
   const uint8_t* Mr = a.b.M + b * D;
   float ll = 0.f;
   for (int d0 = 4 * l; d0 < D; d0 += 4 * LP) {
@@ -285,6 +287,7 @@ __global__ void __launch_bounds__(256) cs_acmwg_accept_kernel(const CsAcmwgArgs 
         if (!bern) *(f32x4_u*)(go + D + d0) = b1;
         if (stt) *(f32x4_u*)(go + 2 * D + d0) = b2;
         *(f32x4_u*)(Xr + d0) = xn4;
+        if (Xc) *(f32x4_u*)(Xc + d0) = xn4;
         if (ring_row) *(f32x4_u*)(ring_row + d0) = xn4;
         if (ring_row8) {
 #pragma unroll
@@ -298,6 +301,7 @@ __global__ void __launch_bounds__(256) cs_acmwg_accept_kernel(const CsAcmwgArgs 
             if (!bern) go[D + d0 + r] = b1[r];
             if (stt) go[2 * D + d0 + r] = b2[r];
             Xr[d0 + r] = xn4[r];
+            if (Xc) Xc[d0 + r] = xn4[r];
             if (ring_row) ring_row[d0 + r] = xn4[r];
             if (ring_row8) ring_row8[d0 + r] = xn4[r] != 0.0f;
           }
@@ -405,8 +409,14 @@ extern "C" int cs_acmwg_init_state(const cs_mlp_t* enc, const cs_mlp_t* dec, con
   return CS_OK;
 }
 
+static int acmwg_step(const cs_mlp_t* enc, const cs_mlp_t* dec, const cs_acmwg_cfg* c, const cs_acmwg_bufs* b,
+                      const cs_rng* rng, float* x_copy, void* stream);
 extern "C" int cs_acmwg_step(const cs_mlp_t* enc, const cs_mlp_t* dec, const cs_acmwg_cfg* c, const cs_acmwg_bufs* b,
                              const cs_rng* rng, void* stream) {
+  return acmwg_step(enc, dec, c, b, rng, nullptr, stream);
+}
+static int acmwg_step(const cs_mlp_t* enc, const cs_mlp_t* dec, const cs_acmwg_cfg* c, const cs_acmwg_bufs* b,
+                      const cs_rng* rng, float* x_copy, void* stream) {
   if (int rc = check_acmwg(c, b)) return rc;
   CS_REQUIRE(enc && dec && b->X && b->M && b->Z_old && b->gen_old && b->z_old_prior_lp && b->x_old_lp && b->q &&
                  b->Z_new && b->gen_new && b->ll_new && b->accepted && b->log_accept,
@@ -425,6 +435,7 @@ extern "C" int cs_acmwg_step(const cs_mlp_t* enc, const cs_mlp_t* dec, const cs_
   hipStream_t st = (hipStream_t)stream;
   CsAcmwgArgs a;
   a.cfg = *c; a.b = *b; a.rng = cs_make_philox(rng);
+  a.x_copy = x_copy;
   const int64_t chains = (int64_t)c->B * c->K;
   if (use_hist || mix) {
     const int ZQ = (c->Zd + 3) / 4;
@@ -506,7 +517,9 @@ extern "C" int cs_acmwg_run(const cs_mlp_t* enc, const cs_mlp_t* dec, const cs_a
     }
     cs_rng rt = r;
     rt.iteration = r.iteration + (uint32_t)t;
-    int rc = cs_acmwg_step(enc, dec, &c, &b, &rt, stream);
+    // (the accept kernel writes the kept copy itself: no copy launch in the chain)
+    float* kept = obs && obs->X_store ? obs->X_store + t * n_x : nullptr;
+    int rc = acmwg_step(enc, dec, &c, &b, &rt, kept, stream);
     if (use_hist) {
       c.hist_tail = (c.hist_tail + 1) % c.hist_len;
       if (c.hist_tail == c.hist_len - 1) c.hist_full = 1;
@@ -515,7 +528,7 @@ extern "C" int cs_acmwg_run(const cs_mlp_t* enc, const cs_mlp_t* dec, const cs_a
         hipMemcpyAsync(out->Z_store + t * n_z, b.Z_old, (size_t)n_z * sizeof(float), hipMemcpyDeviceToDevice,
                        (hipStream_t)stream) != hipSuccess)
       rc = cs_fail(CS_EHIP, "copy of the chain latents into Z_store failed");
-    if (rc == CS_OK) rc = observer.iteration(t, b.X, b.M, (hipStream_t)stream);
+    if (rc == CS_OK) rc = observer.iteration(t, b.X, b.M, (hipStream_t)stream, kept != nullptr);
     if (rc != CS_OK) {
       (void)observer.finish((hipStream_t)stream);
       return rc;
